@@ -1,0 +1,322 @@
+/* zs_amd.h -- C ABI of libzs_amd.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * ASR-TTS autoencoder hot path of andi611/ZeroSpeech-TTS-without-T.
+ *
+ * The reference has no FFI / plugin seam (it is pure Python on torch.nn); this ABI is the inner
+ * seam of the drop-in Python surface (zs_amd.model / zs_amd.trainer / zs_amd.convert).  Each entry
+ * point states which reference arithmetic it replaces (file:line into the reference repository).
+ *
+ * Conventions
+ *  - Every function returns 0 on success or a negative ZS_E* code; zs_last_error() gives text.
+ *    Nothing is thrown across the boundary.
+ *  - The caller owns every buffer (including workspaces).  The library never allocates, frees or
+ *    synchronises; every call only enqueues kernels on `stream` (hipStream_t passed as void*), so
+ *    calls are stream-ordered, re-entrant and hipGraph-capturable.
+ *  - Activations are channels-last: a tensor [B, T, C] is stored as B*T rows of `ld` elements
+ *    (ld >= C, ld a multiple of 32 elements unless stated).  Columns [C, ld) of an activation that
+ *    feeds a GEMM must hold zeros; every kernel here writes them as zeros.
+ *  - dtype: ZS_F32 (exact-fp32 path on v_mfma_f32_32x32x2_f32) or ZS_BF16 (bf16 storage,
+ *    v_mfma_f32_32x32x16_bf16, fp32 accumulate).  Statistics, gradients of parameters, optimizer
+ *    state and losses are always fp32.
+ */
+#ifndef ZS_AMD_H
+#define ZS_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZS_ABI_VERSION 1
+
+enum { ZS_F32 = 0, ZS_BF16 = 1 };
+enum { ZS_OK = 0, ZS_EINVAL = -1, ZS_ELAUNCH = -2, ZS_EWORKSPACE = -3 };
+enum { ZS_PAD_ZERO = 0, ZS_PAD_REFLECT = 1 };
+enum { ZS_ACT_NONE = 0, ZS_ACT_LRELU = 1, ZS_ACT_SIGMOID = 2, ZS_ACT_TANH = 3 };
+enum { ZS_STORE_ROWS = 0, ZS_STORE_SPLIT2 = 1 };   /* SPLIT2 = pixel_shuffle_1d by 2 (see below) */
+enum { ZS_RES_NONE = 0, ZS_RES_IDENTITY = 1, ZS_RES_AVGPOOL2 = 2, ZS_RES_UPSAMPLE2 = 3 };
+
+int zs_abi_version(void);
+const char* zs_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * zs_gemm_conv: implicit-GEMM Conv1d / Linear / transposed-conv (data gradient) on MFMA.
+ *   out[m, n] = epilogue( sum_{j<taps} sum_{ci<cin_pad} A[row(m, j), ci] * W[n, j*cin_pad + ci] )
+ *   m = b*T_out + t.  gather 0 (forward):  row = reflect_or_zero(t*stride + j - pad_left) in [0,T_in)
+ *                     gather 1 (dgrad):    u = t; s = u - j; row = s/stride if s>=0, s%stride==0,
+ *                                          s/stride < T_in, else a zero row.
+ * Replaces: pad_layer()+nn.Conv1d (model/model.py:20-40), linear() (model/model.py:69-78), the GRU
+ * input/recurrent products of nn.GRU (model/model.py:59-66), and their autograd data gradients.
+ * Epilogue order: +bias[n] -> +pre_vec[vec_idx[b]][n] -> act -> *lrelu'(dact_src[m][n]) ->
+ *                 +add_src[m][n] -> store out (-> out2 = value + vec2[vec_idx[b]][col]).
+ * ZS_STORE_SPLIT2 realises pixel_shuffle_1d (model/model.py:43-51) for weights whose output
+ * channels were packed as n' = r*(N/2) + c:  (m, n') -> row 2m + (n' >= N/2), col n' mod (N/2).
+ * `groups` > 1 launches independent problems that differ by the *_gstride element offsets.
+ */
+typedef struct {
+  int32_t dtype;
+  const void* A; int64_t lda; int64_t a_batch_stride;
+  int32_t B, T_in, T_out;
+  int32_t taps, stride, pad_left, pad_mode, gather;
+  int32_t cin_pad;                 /* K per tap, multiple of 32 */
+  const void* W; int64_t ldw;      /* packed [n_pad][ldw], ldw = roundup(taps*cin_pad, 64), zero padded */
+  int32_t N, n_pad;                /* valid columns; packed rows (multiple of 128) */
+  const float* bias;
+  const float* pre_vec; int64_t pre_vec_ld; const int64_t* vec_idx;
+  int32_t act; float slope;
+  const void* dact_src; int64_t dact_ld;
+  const void* add_src; int64_t add_ld; int32_t add_f32;
+  void* out; int64_t ldc; int32_t out_f32; int32_t out_cols; int32_t store_mode;
+  void* out2; int64_t ldc2; int32_t out2_cols; int32_t store_mode2;
+  const float* vec2; int64_t vec2_ld;
+  int32_t groups; int64_t a_gstride, w_gstride, out_gstride, bias_gstride;
+} ZsGemmConv;
+int zs_gemm_conv(const ZsGemmConv* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * zs_gemm_wgrad: weight gradient of the same convolution,
+ *   dW[co, ci, j] = sum_m dY[m, co] * X[row(m, j), ci]        (row() as gather 0 above)
+ * computed as split-K partial slabs [split][co][j][ci_pad] in `workspace` (plain coalesced stores),
+ * then reduced in a fixed order (bitwise reproducible) into dW with element strides (so, si, sj):
+ * Conv1d weight [Cout,Cin,k]: (Cin*k, k, 1); Linear weight [out,in]: (in, 1, 0).
+ * co_split2 un-permutes the SPLIT2 output-channel packing.  accumulate != 0 adds to dW / db.
+ * No atomics anywhere: results are bitwise reproducible run to run.
+ * Replaces: autograd's convolution_backward / addmm weight gradients under loss.backward()
+ * (trainer.py:330).
+ */
+typedef struct {
+  int32_t dtype;
+  const void* dY; int64_t ldy; int32_t y_cols;     /* y_cols: readable columns of dY rows (<= ldy) */
+  const void* X; int64_t ldx; int64_t x_batch_stride; int32_t x_cols;
+  int32_t B, T_in, T_out;
+  int32_t taps, stride, pad_left, pad_mode;
+  int32_t Cout, Cin;
+  float* dW; int64_t so, si, sj;
+  float* db;                       /* optional bias gradient [Cout]: db[co] (+)= sum_m dY[m, co], same slab/reduce path */
+  int32_t co_split2; int32_t accumulate;
+  int32_t splits;                  /* 0 = choose */
+  void* workspace; size_t workspace_bytes;
+} ZsGemmWgrad;
+size_t zs_gemm_wgrad_workspace_bytes(const ZsGemmWgrad* p);
+int zs_gemm_wgrad(const ZsGemmWgrad* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * zs_pack_weight: fp32 parameter (PyTorch layout, strides so/si/sj as above) -> GEMM operand.
+ * Writes the n_rows x n_cols block of dst that starts at (row_offset, col_offset), dst pitch ldw:
+ *   transpose 0 (forward):  block[n][j*inner_pad + ci] = W[co(n)][ci][j]
+ *   transpose 1 (dgrad):    block[ci][j*inner_pad + n] = W[co(n)][ci][j]
+ * co(n) = n, or with co_split2: n < Cout/2 ? 2n : 2(n - Cout/2) + 1.  Everything else in the block is
+ * zero (rows >= Cout|Cin, inner index >= Cin|Cout, taps >= taps).
+ */
+typedef struct {
+  int32_t dtype;
+  const float* W; int64_t so, si, sj;
+  int32_t Cout, Cin, taps;
+  int32_t transpose, co_split2;
+  int32_t inner_pad;               /* cin_pad (transpose 0) or cout_pad (transpose 1) */
+  void* dst; int64_t ldw;
+  int32_t n_rows, n_cols, row_offset, col_offset;
+} ZsPackWeight;
+int zs_pack_weight(const ZsPackWeight* p, void* stream);
+
+/* zs_cast_rows: dst[r][col_off + c] = f(src[r][c]) for c < cols, zeros for cols <= c < fill_cols.
+ * f = identity or leaky_relu (model/model.py:446).  src fp32 or T (src_f32), dst T or fp32. */
+typedef struct {
+  int32_t dtype;
+  const void* src; int64_t ld_src; int32_t src_f32;
+  void* dst; int64_t ld_dst; int32_t dst_f32; int32_t col_off;
+  int64_t rows; int32_t cols, fill_cols;
+  int32_t act; float slope;
+} ZsCastRows;
+int zs_cast_rows(const ZsCastRows* p, void* stream);
+
+/* zs_add_rowvec: out[b,t,c] = x[b,t,c] + vec[idx[b]][c]  (x + emb.view(B,C,1), model/model.py:319,336,353)
+ * x may be null: broadcast (append_emb, model/model.py:81-85). */
+typedef struct {
+  int32_t dtype;
+  const void* x; int64_t ldx;
+  const float* vec; int64_t vec_ld; const int64_t* idx;
+  void* out; int64_t ldo; int32_t B, T, C, fill_cols;   /* C: valid columns of vec; fill_cols: columns written */
+} ZsAddRowvec;
+int zs_add_rowvec(const ZsAddRowvec* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * zs_instnorm_fwd: nn.InstanceNorm1d (no affine, biased var, eps) over T for every (b, c), fused with
+ * nn.Dropout and the block residual (model/model.py:416-438, 317-342):
+ *   out = dropout(xhat) + residual ;  out2 = out + vec2[idx[b]]   (optional)
+ * Dropout keep-mask: `mask` (uint8 [B,T,mask_ld]) if given, else counter-hash RNG(seed, stream_id)
+ * that zs_instnorm_bwd regenerates.  T <= 256.
+ */
+typedef struct {
+  int32_t dtype;
+  const void* x; int64_t ldx;
+  void* out; int64_t ldo;
+  void* out2; int64_t ldo2; const float* vec2; int64_t vec2_ld; int32_t vec2_cols; const int64_t* idx;
+  float* mean; float* rstd;       /* [B][C] fp32, saved for backward (may be null) */
+  int32_t B, T, C; float eps;
+  float drop_p; uint64_t seed; uint32_t stream_id; const uint8_t* mask; int64_t mask_ld;
+  int32_t res_mode; const void* res; int64_t ldres; int32_t T_res; int32_t res_pad_mode;
+} ZsInstNormFwd;
+int zs_instnorm_fwd(const ZsInstNormFwd* p, void* stream);
+
+/* zs_instnorm_bwd: gradient w.r.t. the PRE-activation of the leaky_relu that feeds the norm:
+ *   g = dout * keep/(1-p);  dx = rstd*(g - mean_t(g) - xhat*mean_t(g*xhat));  dz = dx * lrelu'(x). */
+typedef struct {
+  int32_t dtype;
+  const void* dout; int64_t ldd;
+  const void* x; int64_t ldx;
+  const float* mean; const float* rstd;
+  void* dz; int64_t ldz;
+  int32_t B, T, C;
+  float drop_p; uint64_t seed; uint32_t stream_id; const uint8_t* mask; int64_t mask_ld;
+  float slope;
+} ZsInstNormBwd;
+int zs_instnorm_bwd(const ZsInstNormBwd* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * zs_grad_combine: everything autograd does between two GEMMs on the backward path:
+ *   v[b,t,c]  = fold(gp)[b,t,c]                 gp = zs_gemm_conv(gather=1) output over the padded
+ *                                                length T+pad_left+pad_right; reflect pads fold back
+ *   emb_sum[b][c] += sum_t v[b,t,c]              (optional; per-sample part of nn.Embedding backward,
+ *                                                 finished by zs_emb_scatter -- no atomics)
+ *   v += residual term of `res` (IDENTITY: res[t]; AVGPOOL2: 0.5*res[t/2]; UPSAMPLE2: res[2t]+res[2t+1])
+ *   v *= lrelu'(dact_src)                         (optional)
+ *   store: rows, or un-pixel-shuffle (unshuffle=1): (b,t,c) -> row (b, t/2), col (t&1)*C + c
+ */
+typedef struct {
+  int32_t dtype;
+  const void* gp; int64_t ldg; int32_t pad_left, pad_right, pad_mode;
+  int32_t B, T, C;
+  float* emb_sum; int64_t emb_ld; int32_t emb_cols;
+  int32_t res_mode; const void* res; int64_t ldres;
+  const void* dact_src; int64_t dact_ld; float slope;
+  void* out; int64_t ldo; int32_t unshuffle;
+} ZsGradCombine;
+int zs_grad_combine(const ZsGradCombine* p, void* stream);
+
+/* zs_emb_scatter: nn.Embedding weight gradient from per-sample sums, in fixed sample order:
+ *   demb[r][c] (+)= sum_{b : idx[b] == r} emb_sum[b][c]      (model/model.py:310-314 lookups) */
+typedef struct {
+  const float* emb_sum; int64_t emb_ld; const int64_t* idx; int32_t B;
+  float* demb; int64_t demb_ld; int32_t n_rows, C; int32_t accumulate;
+} ZsEmbScatter;
+int zs_emb_scatter(const ZsEmbScatter* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * zs_mbv_fwd / zs_mbv_bwd: Multilabel-Binary-Vector discretiser (model/model.py:93-110, 474-480).
+ * logits rows [B*T'][ld] hold E (l0,l1) pairs.  noise_kind 0: Gumbel noise G given (bit-exact
+ * contract); 1: uniform U given, g = -log(-log(U+1e-20)+1e-20) on device; 2: U from the
+ * counter-hash RNG(seed).  bits = ((hard - y0) + y0) with y = softmax((l+g)/tau), ties -> 1.0
+ * (index 0).  y0 is saved for backward: dl0 = dbits*y0*(1-y0)/tau, dl1 = -dl0.
+ */
+typedef struct {
+  int32_t dtype;
+  const void* logits; int64_t ld; int32_t logits_f32;
+  const float* noise; int32_t noise_kind; uint64_t seed;
+  int64_t rows; int32_t E; float tau;
+  void* bits; int64_t ld_bits; int32_t bits_fill_cols;
+  float* bits_f32;               /* optional compact [rows][E] fp32 copy (API output) */
+  float* y0;                     /* optional [rows][E] */
+} ZsMbvFwd;
+int zs_mbv_fwd(const ZsMbvFwd* p, void* stream);
+typedef struct {
+  int32_t dtype;
+  const void* dbits; int64_t ld_dbits;
+  const float* y0; int64_t rows; int32_t E; float tau;
+  void* dlogits; int64_t ld; int32_t fill_cols;
+} ZsMbvBwd;
+int zs_mbv_bwd(const ZsMbvBwd* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * zs_gru_fwd / zs_gru_bwd: bidirectional single-layer nn.GRU with zero initial state
+ * (model/model.py:59-66, 389, 299), gate order r,z,n.  gi = X W_ih^T + b_ih for BOTH directions
+ * ([B*T][ldgi], columns dir*3H + {r,z,n}*H) comes from zs_gemm_conv.  Per time step the library
+ * enqueues one grouped recurrent product (zs_gemm_conv kernel, 2 directions) and one gate kernel.
+ * out[b,t, out_col + dir*H + j] = h_t.  gates saves r,z,n,(W_hn h + b_hn) for backward.
+ */
+typedef struct {
+  int32_t dtype;
+  int32_t B, T, H;
+  const void* gi; int64_t ldgi;
+  const void* whh; int64_t ldw; int32_t n_pad; int64_t w_gstride;   /* packed fwd [2][n_pad][ldw], N=3H, K=H */
+  const float* bhh; int64_t bhh_gstride;                           /* [2][3H] */
+  void* out; int64_t ldo; int32_t out_col;
+  void* gates; /* T dtype [B][T][2][4H] or null (inference) */
+  float* work; size_t work_bytes;   /* >= zs_gru_work_bytes */
+} ZsGruFwd;
+size_t zs_gru_work_bytes(int32_t B, int32_t H);
+int zs_gru_fwd(const ZsGruFwd* p, void* stream);
+typedef struct {
+  int32_t dtype;
+  int32_t B, T, H;
+  const void* dout; int64_t ldd; int32_t dout_col;   /* gradient w.r.t. out columns */
+  const void* out; int64_t ldo; int32_t out_col;     /* forward outputs (h_t) */
+  const void* gates;
+  const void* whh_t; int64_t ldw; int32_t n_pad; int64_t w_gstride; /* packed transposed [2][n_pad][ldw], N=H, K=3H */
+  void* dgi; int64_t ldgi;       /* [B*T][ldgi] cols dir*3H.. : grad w.r.t. gi (input projections) */
+  void* dgh; int64_t ldgh;       /* same shape: grad w.r.t. (h W_hh^T + b_hh) */
+  float* work; size_t work_bytes;
+} ZsGruBwd;
+int zs_gru_bwd(const ZsGruBwd* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * zs_l1_loss: loss = mean|x_dec - x| over rows*F (trainer.py:328) and the gradient w.r.t. the
+ * pre-sigmoid logits: g = sign(x_dec - x)/(rows*F) * x_dec*(1-x_dec).
+ * loss_out receives the scalar (two-pass, fixed order).  partial: >= 1024 floats.
+ */
+typedef struct {
+  int32_t dtype;
+  const float* x_dec; int64_t ld_dec;
+  const float* x; int64_t ldx;
+  int64_t rows; int32_t F;
+  void* dlogits; int64_t ldg; int32_t fill_cols;   /* may be null (loss only) */
+  float* partial; float* loss_out; float grad_scale;
+} ZsL1Loss;
+int zs_l1_loss(const ZsL1Loss* p, void* stream);
+
+/* zs_sqnorm: out[0] = sum g[i]^2 (double accumulation, fixed order).  partial: >= 1024 doubles. */
+int zs_sqnorm(const float* g, int64_t n, double* partial, float* out_sq, void* stream);
+
+/* zs_adam_clip: nn.utils.clip_grad_norm_(max_norm) (utils.py:53-55) fused with torch.optim.Adam's
+ * single-tensor update (trainer.py:66,332): coef = min(1, max_norm/(sqrt(sumsq)+1e-6)); g *= coef;
+ * m = m + (g-m)(1-b1); v = v*b2 + g*g*(1-b2); p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps).
+ * sumsq is a device scalar (from zs_sqnorm); max_norm <= 0 disables clipping. */
+typedef struct {
+  float* p; float* g; float* m; float* v; int64_t n;
+  float lr, beta1, beta2, eps, bc1, bc2;
+  const float* sumsq; float max_norm; int32_t write_clipped_grad;
+} ZsAdam;
+int zs_adam_clip(const ZsAdam* p, void* stream);
+
+/* zs_softmax_ce: nn.CrossEntropyLoss (mean) + gradient (trainer.py:297-304). logits fp32 [B][ld]. */
+typedef struct {
+  const float* logits; int64_t ld; const int64_t* target; int32_t B, n_class;
+  float* loss_out; float* dlogits; int64_t ldg; float grad_scale; int32_t* correct_out;
+} ZsSoftmaxCE;
+int zs_softmax_ce(const ZsSoftmaxCE* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Vocoder (convert.py:39-62): batched Griffin-Lim on 1024-point real FFTs held in LDS.
+ * mag: fp32 [n_utt][T_max][513] linear magnitudes (zero rows past each utterance's length).
+ * zs_gl_istft: frames of spec (complex64 [n_utt][T_max][513]) -> windowed irfft -> overlap-add /
+ *              window-sum-square -> wav [n_utt][wav_ld] (200*(T-1) samples, centre-trimmed).
+ * zs_gl_stft_project: wav -> reflect-padded frames -> rfft -> spec = mag * E/max(1e-8,|E|).
+ */
+typedef struct {
+  const float* spec; const float* mag; const int32_t* lengths; int32_t n_utt, T_max;
+  float* wav; int64_t wav_ld; float* frames_ws;    /* frames_ws: [n_utt][T_max][1024] fp32 scratch */
+} ZsGlIstft;
+int zs_gl_istft(const ZsGlIstft* p, void* stream);
+typedef struct {
+  const float* wav; int64_t wav_ld; const float* mag; const int32_t* lengths; int32_t n_utt, T_max;
+  float* spec;
+} ZsGlStft;
+int zs_gl_stft_project(const ZsGlStft* p, void* stream);
+/* spectrogram2wav pre/post (convert.py:56-60): de-normalise to amplitude; de-preemphasis IIR. */
+int zs_gl_denormalize(const float* mag_norm, float* mag_amp, int64_t n, void* stream);
+int zs_gl_deemphasis(float* wav, int64_t wav_ld, const int32_t* lengths, int32_t n_utt, float coef, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,435 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (libzs_amd.so) against plain PyTorch fp32 on
+the CPU.  Tolerances: fp32 path 2e-5 relative to the output scale (different summation order only);
+bf16 path: reference computed from bf16-rounded operands, 1.5e-2 relative (bf16 output rounding 2^-8)."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = ['fp32', 'bf16']
+
+
+@pytest.fixture(scope='module')
+def zs():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import zs_amd  # noqa: F401
+    from zs_amd import _lib, layers
+    _lib.lib()
+    return _lib, layers
+
+
+def _ctx(layers, dtype):
+    return layers.Ctx('cuda:0', dtype)
+
+
+def _tol(dtype):
+    return 2e-5 if dtype == 'fp32' else 1.5e-2
+
+
+def _round(t, dtype):
+    return t if dtype == 'fp32' else t.to(torch.bfloat16).float()
+
+
+def _close(name, got, ref, tol):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), name + ': non-finite output'
+    scale = max(1e-6, ref.abs().max().item())
+    err = (got - ref).abs().max().item()
+    if err > tol * scale:
+        idx = np.unravel_index(int((got - ref).abs().argmax()), got.shape)
+        raise AssertionError('%s: max err %.4g > %.4g (scale %.3g) at %s got %.6g ref %.6g' %
+                             (name, err, tol * scale, scale, idx, got[idx].item(), ref[idx].item()))
+
+
+def _to_act(layers, ctx, name, x_btc):
+    """[B,T,C] fp32 cpu -> Act on device in the compute dtype (zero padded)."""
+    B, T, C = x_btc.shape
+    a = ctx.act(name, B, T, C)
+    v = a.t[:B * T * a.ld].view(B * T, a.ld)
+    v.zero_()
+    v[:, :C] = x_btc.reshape(B * T, C).to(ctx.device, a.t.dtype)
+    return a
+
+
+def _mk_conv(layers, ctx, w, b, **kw):
+    dev = ctx.device
+    w_d, b_d = w.to(dev).contiguous(), (b.to(dev).contiguous() if b is not None else None)
+    gw, gb = torch.zeros_like(w_d), (torch.zeros_like(b_d) if b is not None else None)
+    l = layers.ConvLayer(ctx, w_d, b_d, gw, gb, **kw)
+    l.pack()
+    return l
+
+
+def _ref_conv(x_btc, w, b, stride, reflect):
+    k = w.shape[2] if w.dim() == 3 else 1
+    w3 = w if w.dim() == 3 else w.unsqueeze(2)
+    pl, pr = k // 2, k - 1 - k // 2
+    xp = F.pad(x_btc.permute(0, 2, 1), (pl, pr), mode='reflect' if reflect else 'constant')
+    return F.conv1d(xp, w3, b, stride=stride).permute(0, 2, 1)
+
+
+CONV_CASES = [
+    # B, T, Cin, Cout, k, stride, reflect
+    (2, 24, 80, 16, 1, 1, True), (2, 24, 80, 16, 2, 1, True), (2, 24, 80, 16, 3, 1, True), (2, 24, 80, 16, 4, 1, True),
+    (2, 24, 80, 16, 5, 1, True), (2, 24, 80, 16, 6, 1, True), (2, 24, 80, 16, 7, 1, True),
+    (3, 50, 513, 130, 7, 1, True), (2, 9, 32, 32, 5, 2, True), (2, 33, 64, 48, 5, 2, True), (5, 64, 96, 513, 1, 1, True),
+    (2, 20, 32, 40, 3, 1, False), (2, 21, 32, 40, 5, 2, False), (1, 300, 160, 256, 3, 1, True),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_fwd(zs, dtype, case):
+    L, layers = zs
+    B, T, Cin, Cout, k, stride, reflect = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(B, T, Cin, generator=g)
+    w = torch.randn(Cout, Cin, k, generator=g) / math.sqrt(Cin * k)
+    b = torch.randn(Cout, generator=g)
+    ctx = _ctx(layers, dtype)
+    l = _mk_conv(layers, ctx, w, b, stride=stride, pad_mode=L.ZS_PAD_REFLECT if reflect else L.ZS_PAD_ZERO)
+    A = _to_act(layers, ctx, 'x', x)
+    To = l.t_out(T)
+    out = ctx.act('y', B, To, Cout)
+    out.t.fill_(float('nan'))
+    l.fwd(A, out=out, act=L.ZS_ACT_LRELU, slope=0.01)
+    torch.cuda.synchronize()
+    ref = F.leaky_relu(_ref_conv(_round(x, dtype), _round(w, dtype), b, stride, reflect), 0.01)
+    assert ref.shape[1] == To
+    _close('conv', out.valid(), ref, _tol(dtype))
+    full = out.t[:B * To * out.ld].view(B * To, out.ld).float().cpu()
+    assert (full[:, Cout:] == 0).all(), 'pad columns must be written as zeros'
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_conv_epilogue_split2_vec(zs, dtype):
+    """pixel_shuffle + speaker-embedding adds + dual output (decoder conv_block first conv)."""
+    L, layers = zs
+    B, T, C = 3, 10, 32
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, T, C, generator=g)
+    w = torch.randn(2 * C, C, 3, generator=g) / math.sqrt(3 * C)
+    b = torch.randn(2 * C, generator=g)
+    emb = torch.randn(4, C, generator=g)
+    cidx = torch.tensor([2, 0, 3])
+    ctx = _ctx(layers, dtype)
+    l = _mk_conv(layers, ctx, w, b, split2=True)
+    A = _to_act(layers, ctx, 'x', x)
+    ya = ctx.act('ya', B, T, 2 * C)
+    s = ctx.act('s', B, 2 * T, C)
+    l.fwd(A, out=ya, act=L.ZS_ACT_LRELU, slope=0.01, out2=s, vec2=emb.to(ctx.device), idx=cidx.to(ctx.device),
+          store_mode2=L.ZS_STORE_SPLIT2)
+    torch.cuda.synchronize()
+    y = F.leaky_relu(_ref_conv(_round(x, dtype), _round(w, dtype), b, 1, True), 0.01)       # [B,T,2C] reference channel order
+    y_bct = y.permute(0, 2, 1)
+    shuf = y_bct.contiguous().view(B, C, 2, T).permute(0, 1, 3, 2).contiguous().view(B, C, 2 * T)   # model/model.py:43-51
+    ref_s = (shuf + emb[cidx].unsqueeze(2)).permute(0, 2, 1)
+    _close('shuffle+emb', s.valid(), ref_s, _tol(dtype))
+    perm = torch.cat([torch.arange(0, 2 * C, 2), torch.arange(1, 2 * C, 2)])
+    _close('ya (packed order)', ya.valid(), y[:, :, perm], _tol(dtype))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', [(2, 16, 32, 48, 5, 1), (2, 16, 32, 48, 5, 2), (3, 12, 64, 32, 3, 1), (2, 10, 40, 24, 1, 1),
+                                  (2, 128, 96, 80, 5, 2)])
+def test_conv_backward(zs, dtype, case):
+    """dgrad (padded domain) + reflect fold + lrelu' ; wgrad ; bias grad -- against autograd."""
+    L, layers = zs
+    B, T, Cin, Cout, k, stride = case
+    g = torch.Generator().manual_seed(11)
+    x = _round(torch.randn(B, T, Cin, generator=g), dtype).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, k, generator=g) / math.sqrt(Cin * k))
+    wr = _round(w, dtype).requires_grad_(True)
+    b = torch.randn(Cout, generator=g).requires_grad_(True)
+    y = _ref_conv(x, wr, b, stride, True)
+    dy = _round(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+    ctx = _ctx(layers, dtype)
+    l = _mk_conv(layers, ctx, w, b.detach(), stride=stride)
+    X = _to_act(layers, ctx, 'x', x.detach())
+    dY = _to_act(layers, ctx, 'dy', dy)
+    gp = ctx.act('gp', B, T + l.pad_l + l.pad_r, Cin)
+    l.dgrad(dY, T, gp)
+    dx = ctx.act('dx', B, T, Cin)
+    L.call('zs_grad_combine', 'ZsGradCombine', ctx.stream, dtype=ctx.dt, gp=gp.ptr(), ldg=gp.ld, pad_left=l.pad_l,
+           pad_right=l.pad_r, pad_mode=L.ZS_PAD_REFLECT, B=B, T=T, C=gp.ld, res_mode=L.ZS_RES_NONE, out=dx.ptr(), ldo=dx.ld)
+    l.wgrad(dY, X)
+    torch.cuda.synchronize()
+    _close('dx', dx.valid(), x.grad, _tol(dtype))
+    _close('dW', l.gw, wr.grad, _tol(dtype))
+    _close('db', l.gb, b.grad, _tol(dtype))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_wgrad_split2_and_shift(zs, dtype):
+    L, layers = zs
+    B, T, Cin, C = 2, 12, 32, 16
+    g = torch.Generator().manual_seed(5)
+    x = _round(torch.randn(B, T, Cin, generator=g), dtype)
+    w = torch.randn(2 * C, Cin, 3, generator=g)
+    dy_ref = _round(torch.randn(B, T, 2 * C, generator=g), dtype)      # reference channel order
+    perm = torch.cat([torch.arange(0, 2 * C, 2), torch.arange(1, 2 * C, 2)])
+    ctx = _ctx(layers, dtype)
+    l = _mk_conv(layers, ctx, w, torch.zeros(2 * C), split2=True)
+    l.wgrad(_to_act(layers, ctx, 'dy', dy_ref[:, :, perm]), _to_act(layers, ctx, 'x', x))
+    wr = w.clone().requires_grad_(True)
+    b = torch.zeros(2 * C, requires_grad=True)
+    _ref_conv(x, wr, b, 1, True).backward(dy_ref)
+    torch.cuda.synchronize()
+    _close('dW split2', l.gw, wr.grad, _tol(dtype))
+    _close('db split2', l.gb, b.grad, _tol(dtype))
+    # shifted zero-padded gather (GRU dW_hh: h_{t-1} / h_{t+1})
+    H = 16
+    hbuf = _round(torch.randn(B, T, H, generator=g), dtype)
+    dgh = _round(torch.randn(B, T, 3 * H, generator=g), dtype)
+    Hh, D = _to_act(layers, ctx, 'h', hbuf), _to_act(layers, ctx, 'dgh', dgh)
+    for shift, pad_left in ((-1, 1), (1, -1)):
+        dW = torch.zeros(3 * H, H, device=ctx.device)
+        layers.wgrad_call(ctx, dict(dtype=ctx.dt, dY=D.ptr(), ldy=D.ld, y_cols=D.ld, X=Hh.ptr(), ldx=Hh.ld, x_batch_stride=T * Hh.ld,
+                                    x_cols=Hh.ld, B=B, T_in=T, T_out=T, taps=1, stride=1, pad_left=pad_left, pad_mode=L.ZS_PAD_ZERO,
+                                    Cout=3 * H, Cin=H, dW=L.ptr(dW), so=H, si=1, sj=0, co_split2=0, accumulate=0, splits=0))
+        hs = torch.zeros_like(hbuf)
+        if shift == -1:
+            hs[:, 1:] = hbuf[:, :-1]
+        else:
+            hs[:, :-1] = hbuf[:, 1:]
+        ref = torch.einsum('btn,bth->nh', dgh, hs)
+        torch.cuda.synchronize()
+        _close('dW_hh shift %d' % shift, dW, ref, _tol(dtype))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('res', ['none', 'identity', 'avgpool', 'avgpool_odd', 'upsample'])
+def test_instnorm(zs, dtype, res):
+    L, layers = zs
+    B, T, C, p = 3, 20, 40, 0.5
+    g = torch.Generator().manual_seed(7)
+    x = _round(F.leaky_relu(torch.randn(B, T, C, generator=g), 0.01), dtype).requires_grad_(True)
+    mask = (torch.rand(B, T, C, generator=g) >= p)
+    Tr = {'none': T, 'identity': T, 'avgpool': 2 * T, 'avgpool_odd': 2 * T - 1, 'upsample': T // 2}[res]
+    r = _round(torch.randn(B, Tr, C, generator=g), dtype)
+    xb = x.permute(0, 2, 1)
+    mean = xb.mean(2, keepdim=True)
+    xh = (xb - mean) / torch.sqrt(((xb - mean) ** 2).mean(2, keepdim=True) + 1e-5)
+    y = xh * mask.permute(0, 2, 1) / (1 - p)
+    rb = r.permute(0, 2, 1)
+    if res == 'identity':
+        y = y + rb
+    elif res.startswith('avgpool'):
+        y = y + F.avg_pool1d(F.pad(rb, (0, Tr % 2), mode='reflect'), 2)
+    elif res == 'upsample':
+        y = y + rb.repeat_interleave(2, dim=2)
+    y = y.permute(0, 2, 1)
+    dout = _round(torch.randn(B, T, C, generator=g), dtype)
+    y.backward(dout)
+    # dz = dx * lrelu'(x): autograd through x = lrelu(z) is emulated by multiplying with lrelu'(x)
+    ref_dz = x.grad * torch.where(x.detach() > 0, torch.ones(()), torch.tensor(0.01))
+    ctx = _ctx(layers, dtype)
+    X, R, D = _to_act(layers, ctx, 'x', x.detach()), _to_act(layers, ctx, 'r', r), _to_act(layers, ctx, 'd', dout)
+    out, dz = ctx.act('o', B, T, C), ctx.act('dz', B, T, C)
+    Cp = X.ld
+    mean_b, rstd_b = ctx.f32('mean', B * Cp), ctx.f32('rstd', B * Cp)
+    m8 = mask.to(torch.uint8).contiguous().to(ctx.device)
+    mode = {'none': L.ZS_RES_NONE, 'identity': L.ZS_RES_IDENTITY, 'avgpool': L.ZS_RES_AVGPOOL2, 'avgpool_odd': L.ZS_RES_AVGPOOL2,
+            'upsample': L.ZS_RES_UPSAMPLE2}[res]
+    L.call('zs_instnorm_fwd', 'ZsInstNormFwd', ctx.stream, dtype=ctx.dt, x=X.ptr(), ldx=X.ld, out=out.ptr(), ldo=out.ld,
+           mean=L.ptr(mean_b), rstd=L.ptr(rstd_b), B=B, T=T, C=Cp, eps=1e-5, drop_p=p, mask=L.ptr(m8), mask_ld=C,
+           res_mode=mode, res=R.ptr(), ldres=R.ld, T_res=Tr, res_pad_mode=L.ZS_PAD_REFLECT)
+    L.call('zs_instnorm_bwd', 'ZsInstNormBwd', ctx.stream, dtype=ctx.dt, dout=D.ptr(), ldd=D.ld, x=X.ptr(), ldx=X.ld,
+           mean=L.ptr(mean_b), rstd=L.ptr(rstd_b), dz=dz.ptr(), ldz=dz.ld, B=B, T=T, C=Cp, drop_p=p, mask=L.ptr(m8), mask_ld=C,
+           slope=0.01)
+    torch.cuda.synchronize()
+    _close('instnorm fwd ' + res, out.valid(), y, _tol(dtype))
+    _close('instnorm bwd ' + res, dz.valid(), ref_dz, max(_tol(dtype), 1e-4))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_instnorm_rng_dropout_consistency(zs, dtype):
+    """Counter-hash dropout: fwd and bwd regenerate the same mask; keep rate ~ 1-p."""
+    L, layers = zs
+    B, T, C, p = 4, 64, 64, 0.5
+    ctx = _ctx(layers, dtype)
+    x = torch.randn(B, T, C)
+    X = _to_act(layers, ctx, 'x', x)
+    out, dz = ctx.act('o', B, T, C), ctx.act('dz', B, T, C)
+    ones = _to_act(layers, ctx, 'ones', torch.ones(B, T, C))
+    mean_b, rstd_b = ctx.f32('mean', B * C), ctx.f32('rstd', B * C)
+    kw = dict(dtype=ctx.dt, B=B, T=T, C=C, drop_p=p, seed=1234, stream_id=3)
+    L.call('zs_instnorm_fwd', 'ZsInstNormFwd', ctx.stream, x=X.ptr(), ldx=X.ld, out=out.ptr(), ldo=out.ld, mean=L.ptr(mean_b),
+           rstd=L.ptr(rstd_b), eps=1e-5, res_mode=L.ZS_RES_NONE, **kw)
+    torch.cuda.synchronize()
+    o = out.valid().float().cpu()
+    keep = (o != 0)
+    assert abs(keep.float().mean().item() - (1 - p)) < 0.02
+    xh = (x - x.mean(1, keepdim=True)) / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-5)
+    _close('kept values', o[keep], (xh / (1 - p))[keep], _tol(dtype))
+
+
+def test_mbv_bit_exact_and_grad(zs):
+    L, layers = zs
+    import zs_oracle as O
+    torch.manual_seed(0)
+    rows, E = 37, 24
+    logits = torch.randn(rows, 2 * E) * 3
+    U = torch.rand(rows, E, 2)
+    G = O.gumbel_from_uniform(U)
+    lg = logits.view(rows, E, 2).clone().requires_grad_(True)
+    out, y = O.gumbel_softmax_hard(lg, G)
+    dbits = torch.randn(rows, E)
+    out[..., 0].backward(dbits)
+    ctx = _ctx(layers, 'fp32')
+    dev = ctx.device
+    bits_f = torch.zeros(rows, E, device=dev)
+    y0 = torch.zeros(rows, E, device=dev)
+    lgd = logits.to(dev)
+    for kind, noise in ((0, G), (1, U)):
+        noise_d = noise.to(dev).contiguous()           # keep alive: the call only takes raw pointers
+        L.call('zs_mbv_fwd', 'ZsMbvFwd', ctx.stream, dtype=ctx.dt, logits=L.ptr(lgd), ld=2 * E, logits_f32=1, noise=L.ptr(noise_d),
+               noise_kind=kind, rows=rows, E=E, tau=0.1, bits_f32=L.ptr(bits_f), y0=L.ptr(y0))
+        torch.cuda.synchronize()
+        flips = (bits_f.cpu() != out[..., 0].detach())
+        if kind == 0:
+            assert not flips.any(), 'MBV bits must be bit-exact given (logits, G)'
+            assert torch.equal(bits_f.cpu(), out[..., 0].detach())          # values are exactly 0.0 / 1.0
+        else:
+            s = (logits.view(rows, E, 2) + G)
+            assert (not flips.any()) or (s[..., 0] - s[..., 1]).abs()[flips].max() < 1e-4
+    _close('y0', y0, y[..., 0].detach(), 1e-5)
+    db = torch.zeros(rows, 32, device=dev)
+    db[:, :E] = dbits.to(dev)
+    dl = torch.zeros(rows, 64, device=dev)
+    L.call('zs_mbv_bwd', 'ZsMbvBwd', ctx.stream, dtype=ctx.dt, dbits=L.ptr(db), ld_dbits=32, y0=L.ptr(y0), rows=rows, E=E, tau=0.1,
+           dlogits=L.ptr(dl), ld=64, fill_cols=64)
+    torch.cuda.synchronize()
+    _close('dlogits', dl[:, :2 * E], lg.grad.reshape(rows, 2 * E), 1e-4)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(3, 5, 24, 16), (2, 16, 32, 32)])
+def test_gru(zs, dtype, shape):
+    """Bidirectional GRU forward + BPTT + all parameter gradients vs. the oracle GRU under autograd."""
+    L, layers = zs
+    import zs_oracle as O
+    B, T, Cin, H = shape
+    g = torch.Generator().manual_seed(2)
+    names = ['weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0']
+    P = {}
+    for sfx in ('', '_reverse'):
+        P['RNN.weight_ih_l0' + sfx] = torch.randn(3 * H, Cin, generator=g) / math.sqrt(Cin)
+        P['RNN.weight_hh_l0' + sfx] = torch.randn(3 * H, H, generator=g) / math.sqrt(H)
+        P['RNN.bias_ih_l0' + sfx] = torch.randn(3 * H, generator=g) * 0.1
+        P['RNN.bias_hh_l0' + sfx] = torch.randn(3 * H, generator=g) * 0.1
+    x = _round(torch.randn(B, T, Cin, generator=g), dtype)
+    Pr = {k: (_round(v, dtype) if 'weight' in k else v).clone().requires_grad_(True) for k, v in P.items()}
+    xr = x.clone().requires_grad_(True)
+    out = O.bigru(xr.permute(0, 2, 1), Pr, 'RNN.').permute(0, 2, 1)          # [B,T,2H]
+    dout = _round(torch.randn(B, T, 2 * H, generator=g), dtype)
+    out.backward(dout)
+    ctx = _ctx(layers, dtype)
+    dev = ctx.device
+    Pd = {k: v.to(dev).contiguous() for k, v in P.items()}
+    Gd = {k: torch.zeros_like(v) for k, v in Pd.items()}
+    gru = layers.GruLayer(ctx, Pd, Gd, 'RNN.', name='t')
+    gru.pack()
+    X = _to_act(layers, ctx, 'x', x)
+    cat = ctx.act('cat', B, T, Cin + 2 * H)
+    gi = ctx.act('gi', B, T, 6 * H)
+    gates = ctx.raw('gates', B * T * 8 * H, ctx.tdt)
+    gru.fwd(X, cat, Cin, gi, gates)
+    torch.cuda.synchronize()
+    got = cat.valid()[:, :, Cin:]
+    _close('gru fwd', got, out, 4 * _tol(dtype))
+    dcat = _to_act(layers, ctx, 'dcat', torch.cat([torch.zeros(B, T, Cin), dout], dim=2))
+    dgi, dgh = ctx.act('dgi', B, T, 6 * H), ctx.act('dgh', B, T, 6 * H)
+    dX = ctx.act('dX', B, T, Cin)
+    gru.bwd(dcat, Cin, cat, Cin, gates, X, dgi, dgh, dX)
+    torch.cuda.synchronize()
+    tol = 6 * _tol(dtype)
+    _close('gru dX', dX.valid(), xr.grad, tol)
+    for k in P:
+        _close('gru grad ' + k, Gd[k], Pr[k].grad, tol)
+
+
+def test_loss_norm_adam(zs):
+    L, layers = zs
+    torch.manual_seed(1)
+    ctx = _ctx(layers, 'fp32')
+    dev = ctx.device
+    rows, Fv = 50, 80
+    xd = torch.rand(rows, 96)
+    x = torch.rand(rows, Fv)
+    z = torch.logit(xd[:, :Fv].clamp(1e-4, 1 - 1e-4)).requires_grad_(True)
+    loss = torch.mean(torch.abs(torch.sigmoid(z) - x))
+    loss.backward()
+    xdd, xx = torch.sigmoid(z.detach()), x
+    xd[:, :Fv] = xdd
+    dl = torch.full((rows, 96), float('nan'), device=dev)
+    part, lo = torch.zeros(1024, device=dev), torch.zeros(1, device=dev)
+    xd_d, xx_d = xd.to(dev), xx.to(dev)                # keep alive: the call only takes raw pointers
+    L.call('zs_l1_loss', 'ZsL1Loss', ctx.stream, dtype=ctx.dt, x_dec=L.ptr(xd_d), ld_dec=96, x=L.ptr(xx_d), ldx=Fv, rows=rows,
+           F=Fv, dlogits=L.ptr(dl), ldg=96, fill_cols=96, partial=L.ptr(part), loss_out=L.ptr(lo), grad_scale=1.0)
+    torch.cuda.synchronize()
+    assert abs(lo.item() - loss.item()) < 1e-6
+    _close('dlogit', dl[:, :Fv], z.grad, 1e-5)
+    assert (dl[:, Fv:] == 0).all()
+    # sqnorm + clip + Adam against torch.optim.Adam / clip_grad_norm_
+    n = 10007
+    p0, g0 = torch.randn(n), torch.randn(n) * 3
+    for max_norm in (5.0, 1e9):
+        p = torch.nn.Parameter(p0.clone())
+        opt = torch.optim.Adam([p], lr=1e-3, betas=(0.5, 0.9))
+        pd, gd = p0.clone().to(dev), None
+        m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        sq, dpart = torch.zeros(1, device=dev), torch.zeros(1024, dtype=torch.float64, device=dev)
+        for step in range(1, 4):
+            g = g0 * step
+            p.grad = g.clone()
+            tn = torch.nn.utils.clip_grad_norm_([p], max_norm)
+            opt.step()
+            gd = g.clone().to(dev)
+            L.check(L.lib().zs_sqnorm(L.ptr(gd), n, L.ptr(dpart), L.ptr(sq), ctx.stream), 'sqnorm')
+            L.call('zs_adam_clip', 'ZsAdam', ctx.stream, p=L.ptr(pd), g=L.ptr(gd), m=L.ptr(m), v=L.ptr(v), n=n, lr=1e-3, beta1=0.5,
+                   beta2=0.9, eps=1e-8, bc1=1 - 0.5 ** step, bc2=1 - 0.9 ** step, sumsq=L.ptr(sq), max_norm=max_norm)
+            torch.cuda.synchronize()
+            assert abs(math.sqrt(sq.item()) - tn.item()) < 1e-4 * tn.item()
+            _close('adam p step %d' % step, pd, p.detach(), 2e-6)
+
+
+def test_pack_weight_known_answer(zs):
+    L, layers = zs
+    ctx = _ctx(layers, 'fp32')
+    w = torch.arange(4 * 3 * 2, dtype=torch.float32).view(4, 3, 2)       # [Cout=4, Cin=3, k=2]
+    l = _mk_conv(layers, ctx, w, None)
+    torch.cuda.synchronize()
+    wf = l.wf[:l.n_pad * l.ldw].view(l.n_pad, l.ldw).cpu()
+    for n in range(4):
+        for ci in range(3):
+            for j in range(2):
+                assert wf[n, j * l.cin_pad + ci] == w[n, ci, j]
+    assert wf.sum() == w.sum()
+    wd = l.wd[:l.n_pad_d * l.ldw_d].view(l.n_pad_d, l.ldw_d).cpu()
+    for n in range(4):
+        for ci in range(3):
+            for j in range(2):
+                assert wd[ci, j * l.cout_pad + n] == w[n, ci, j]
+    assert wd.sum() == w.sum()
+
+
+def test_errors_are_loud(zs):
+    L, layers = zs
+    ctx = _ctx(layers, 'fp32')
+    with pytest.raises(L.ZsError):
+        L.call('zs_gemm_conv', 'ZsGemmConv', ctx.stream, dtype=0)            # null operands
+    w = torch.randn(8, 32, 5)
+    l = _mk_conv(layers, ctx, w, torch.zeros(8))
+    A = _to_act(layers, ctx, 'x', torch.randn(1, 2, 32))
+    out = ctx.act('y', 1, 2, 8)
+    with pytest.raises(L.ZsError, match='Padding size should be less'):     # same failure the reference hits for T' = 2
+        l.fwd(A, out=out)

@@ -1,0 +1,336 @@
+// zs_elem.hip -- HBM-bound elementwise / reduction kernels of the autoencoder path: weight packing,
+// casts, speaker-embedding adds and gradient scatter, the MBV discretiser, L1 loss, grad-norm, Adam, CE.
+#include "zs_common.h"
+
+namespace {
+
+constexpr int NTE = 256;
+
+template <typename T> __device__ __forceinline__ float ldT(const void* p, int64_t i) { return Elem<T>::ld((const T*)p + i); }
+template <typename T> __device__ __forceinline__ void stT(void* p, int64_t i, float v) { Elem<T>::st((T*)p + i, v); }
+
+// ---- pack_weight ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_weight_kernel(const ZsPackWeight p) {
+  const int64_t total = (int64_t)p.n_rows * p.n_cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / p.n_cols);
+    const int k = (int)(i - (int64_t)row * p.n_cols);
+    const int tap = k / p.inner_pad, inner = k - tap * p.inner_pad;
+    int n, ci;
+    if (p.transpose == 0) { n = row; ci = inner; } else { n = inner; ci = row; }
+    float v = 0.f;
+    if (n < p.Cout && ci < p.Cin && tap < p.taps) {
+      const int half = p.Cout >> 1;
+      const int co = p.co_split2 ? (n < half ? 2 * n : 2 * (n - half) + 1) : n;
+      v = p.W[(int64_t)co * p.so + (int64_t)ci * p.si + (int64_t)tap * p.sj];
+    }
+    stT<T>(p.dst, (int64_t)(row + p.row_offset) * p.ldw + p.col_offset + k, v);
+  }
+}
+
+// ---- cast_rows -------------------------------------------------------------------------------------
+template <typename T>
+__global__ void cast_rows_kernel(const ZsCastRows p) {
+  const int64_t total = p.rows * p.fill_cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / p.fill_cols;
+    const int c = (int)(i - r * p.fill_cols);
+    float v = 0.f;
+    if (c < p.cols) {
+      v = p.src_f32 ? ((const float*)p.src)[r * p.ld_src + c] : ldT<T>(p.src, r * p.ld_src + c);
+      if (p.act == ZS_ACT_LRELU) v = lrelu_f(v, p.slope);
+    }
+    if (p.dst_f32) ((float*)p.dst)[r * p.ld_dst + p.col_off + c] = v; else stT<T>(p.dst, r * p.ld_dst + p.col_off + c, v);
+  }
+}
+
+// ---- add_rowvec ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void add_rowvec_kernel(const ZsAddRowvec p) {
+  const int64_t rows = (int64_t)p.B * p.T;
+  const int64_t total = rows * p.fill_cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / p.fill_cols;
+    const int c = (int)(i - r * p.fill_cols);
+    const int b = (int)(r / p.T);
+    float v = p.x ? ldT<T>(p.x, r * p.ldx + c) : 0.f;
+    if (c < p.C) v += p.vec[p.idx[b] * p.vec_ld + c];
+    stT<T>(p.out, r * p.ldo + c, v);
+  }
+}
+
+// ---- embedding scatter (fixed sample order, no atomics) ---------------------------------------------
+__global__ void emb_scatter_kernel(const ZsEmbScatter p) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  if (c >= p.C) return;
+  float s = 0.f;
+  for (int b = 0; b < p.B; ++b)
+    if (p.idx[b] == (int64_t)r) s += p.emb_sum[(int64_t)b * p.emb_ld + c];
+  float* d = p.demb + (int64_t)r * p.demb_ld + c;
+  *d = p.accumulate ? (*d + s) : s;
+}
+
+// ---- MBV ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void mbv_fwd_kernel(const ZsMbvFwd p) {
+  const int64_t total = p.rows * p.bits_fill_cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / p.bits_fill_cols;
+    const int e = (int)(i - r * p.bits_fill_cols);
+    float bit = 0.f;
+    if (e < p.E) {
+      float l0, l1;
+      if (p.logits_f32) { l0 = ((const float*)p.logits)[r * p.ld + 2 * e]; l1 = ((const float*)p.logits)[r * p.ld + 2 * e + 1]; }
+      else { l0 = ldT<T>(p.logits, r * p.ld + 2 * e); l1 = ldT<T>(p.logits, r * p.ld + 2 * e + 1); }
+      const int64_t ni = (r * p.E + e) * 2;
+      float g0, g1;
+      if (p.noise_kind == 0) { g0 = p.noise[ni]; g1 = p.noise[ni + 1]; }
+      else {
+        float u0, u1;
+        if (p.noise_kind == 1) { u0 = p.noise[ni]; u1 = p.noise[ni + 1]; }
+        else { u0 = zs_uniform(p.seed, 0x6d627600u, (uint64_t)ni); u1 = zs_uniform(p.seed, 0x6d627600u, (uint64_t)ni + 1); }
+        g0 = -logf(-logf(u0 + 1e-20f) + 1e-20f);                 // model/model.py:95-98
+        g1 = -logf(-logf(u1 + 1e-20f) + 1e-20f);
+      }
+      const float a0 = __fdiv_rn(__fadd_rn(l0, g0), p.tau);     // (logits + G) / temperature, true fp32 division
+      const float a1 = __fdiv_rn(__fadd_rn(l1, g1), p.tau);
+      const float mx = fmaxf(a0, a1);
+      const float e0 = expf(a0 - mx), e1 = expf(a1 - mx);
+      const float sum = __fadd_rn(e0, e1);
+      const float y0 = __fdiv_rn(e0, sum), y1 = __fdiv_rn(e1, sum);
+      const float hard = (y0 >= y1) ? 1.f : 0.f;                 // argmax, first index on ties
+      bit = __fadd_rn(__fsub_rn(hard, y0), y0);                  // (y_hard - y).detach() + y
+      if (p.bits_f32) p.bits_f32[r * p.E + e] = bit;
+      if (p.y0) p.y0[r * p.E + e] = y0;
+    }
+    if (p.bits) stT<T>(p.bits, r * p.ld_bits + e, bit);
+  }
+}
+
+template <typename T>
+__global__ void mbv_bwd_kernel(const ZsMbvBwd p) {
+  const int64_t total = p.rows * (p.fill_cols / 2);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / (p.fill_cols / 2);
+    const int e = (int)(i - r * (p.fill_cols / 2));
+    float d0 = 0.f;
+    if (e < p.E) {
+      const float y0 = p.y0[r * p.E + e];
+      d0 = ldT<T>(p.dbits, r * p.ld_dbits + e) * y0 * (1.f - y0) / p.tau;
+    }
+    stT<T>(p.dlogits, r * p.ld + 2 * e, d0);
+    stT<T>(p.dlogits, r * p.ld + 2 * e + 1, -d0);
+  }
+}
+
+// ---- L1 loss -----------------------------------------------------------------------------------------
+template <typename T>
+__global__ void l1_stage1_kernel(const ZsL1Loss p) {
+  __shared__ float red[NTE / 64];
+  const int64_t total = p.rows * p.fill_cols;
+  const float gs = p.grad_scale / ((float)p.rows * (float)p.F);
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / p.fill_cols;
+    const int c = (int)(i - r * p.fill_cols);
+    float g = 0.f;
+    if (c < p.F) {
+      const float xd = p.x_dec[r * p.ld_dec + c];
+      const float d = xd - p.x[r * p.ldx + c];
+      s += fabsf(d);
+      g = (d > 0.f ? gs : (d < 0.f ? -gs : 0.f)) * xd * (1.f - xd);
+    }
+    if (p.dlogits) stT<T>(p.dlogits, r * p.ldg + c, g);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { float t = 0.f; for (int w = 0; w < NTE / 64; ++w) t += red[w]; p.partial[blockIdx.x] = t; }
+}
+__global__ void l1_stage2_kernel(const float* partial, int n, float* out, double denom) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += (double)partial[i];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = (float)((red[0] + red[1] + red[2] + red[3]) / denom);
+}
+
+// ---- squared norm --------------------------------------------------------------------------------------
+__global__ void sqnorm_stage1_kernel(const float* g, int64_t n, double* partial) {
+  __shared__ double red[NTE / 64];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = g[i]; s += (double)v * (double)v;
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < NTE / 64; ++w) t += red[w]; partial[blockIdx.x] = t; }
+}
+__global__ void sqnorm_stage2_kernel(const double* partial, int n, float* out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += partial[i];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+
+// ---- Adam + clip -------------------------------------------------------------------------------------
+__global__ void adam_kernel(const ZsAdam p) {
+  float coef = 1.f;
+  if (p.max_norm > 0.f && p.sumsq) {
+    const float norm = sqrtf(*p.sumsq);
+    coef = fminf(p.max_norm / (norm + 1e-6f), 1.f);              // clip_grad_norm_
+  }
+  const float step_size = p.lr / p.bc1;
+  const float bc2_sqrt = sqrtf(p.bc2);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float g = p.g[i] * coef;
+    float m = p.m[i], v = p.v[i];
+    m = m + (g - m) * (1.f - p.beta1);                           // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * p.beta2 + g * g * (1.f - p.beta2);                   // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+    const float denom = sqrtf(v) / bc2_sqrt + p.eps;
+    p.p[i] = p.p[i] - step_size * (m / denom);
+    p.m[i] = m; p.v[i] = v;
+    if (p.write_clipped_grad) p.g[i] = g;
+  }
+}
+
+// ---- softmax cross-entropy ----------------------------------------------------------------------------
+__global__ void softmax_ce_kernel(const ZsSoftmaxCE p) {
+  __shared__ float red[4];
+  __shared__ int redc[4];
+  float ls = 0.f; int corr = 0;
+  for (int b = threadIdx.x; b < p.B; b += blockDim.x) {
+    const float* l = p.logits + (int64_t)b * p.ld;
+    float mx = l[0]; int am = 0;
+    for (int j = 1; j < p.n_class; ++j) if (l[j] > mx) { mx = l[j]; am = j; }
+    float se = 0.f;
+    for (int j = 0; j < p.n_class; ++j) se += expf(l[j] - mx);
+    const int t = (int)p.target[b];
+    ls += (logf(se) + mx) - l[t];
+    corr += (am == t);
+    if (p.dlogits) {
+      const float gs = p.grad_scale / (float)p.B;
+      for (int j = 0; j < p.n_class; ++j)
+        p.dlogits[(int64_t)b * p.ldg + j] = (expf(l[j] - mx) / se - (j == t ? 1.f : 0.f)) * gs;
+    }
+  }
+  ls = wave_sum(ls);
+  corr = (int)wave_sum((float)corr);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = ls; redc[threadIdx.x >> 6] = corr; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *p.loss_out = (red[0] + red[1] + red[2] + red[3]) / (float)p.B;
+    if (p.correct_out) *p.correct_out = redc[0] + redc[1] + redc[2] + redc[3];
+  }
+}
+
+inline unsigned nblocks(int64_t total, int cap = 2048) {
+  int64_t b = (total + NTE - 1) / NTE;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+#define ZS_DISPATCH(dtype, KERNEL, grid, block, stream, ...)                                            \
+  do {                                                                                                  \
+    if ((dtype) == ZS_F32) hipLaunchKernelGGL(KERNEL<float>, grid, block, 0, (hipStream_t)(stream), __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL<bf16_t>, grid, block, 0, (hipStream_t)(stream), __VA_ARGS__);          \
+  } while (0)
+
+extern "C" int zs_pack_weight(const ZsPackWeight* p, void* stream) {
+  ZS_REQUIRE(p && p->W && p->dst, "zs_pack_weight: null operand");
+  ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_pack_weight: bad dtype");
+  ZS_REQUIRE(p->Cout > 0 && p->Cin > 0 && p->taps > 0 && p->inner_pad > 0 && p->n_rows > 0 && p->n_cols > 0 &&
+                 p->ldw >= (int64_t)p->col_offset + p->n_cols && p->n_cols >= p->taps * p->inner_pad,
+             "zs_pack_weight: sizes (ldw %lld n_cols %d taps %d inner_pad %d)", (long long)p->ldw, p->n_cols, p->taps, p->inner_pad);
+  ZS_REQUIRE((p->transpose ? p->Cout : p->Cin) <= p->inner_pad, "zs_pack_weight: inner_pad too small");
+  ZS_REQUIRE(!p->co_split2 || p->Cout % 2 == 0, "zs_pack_weight: SPLIT2 needs even Cout");
+  ZS_DISPATCH(p->dtype, pack_weight_kernel, dim3(nblocks((int64_t)p->n_rows * p->n_cols, 4096)), dim3(NTE), stream, *p);
+  return zs_check_launch("zs_pack_weight");
+}
+
+extern "C" int zs_cast_rows(const ZsCastRows* p, void* stream) {
+  ZS_REQUIRE(p && p->src && p->dst && p->rows > 0 && p->cols > 0 && p->fill_cols >= p->cols, "zs_cast_rows: bad args");
+  ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_cast_rows: bad dtype");
+  ZS_DISPATCH(p->dtype, cast_rows_kernel, dim3(nblocks(p->rows * p->fill_cols, 4096)), dim3(NTE), stream, *p);
+  return zs_check_launch("zs_cast_rows");
+}
+
+extern "C" int zs_add_rowvec(const ZsAddRowvec* p, void* stream) {
+  ZS_REQUIRE(p && p->vec && p->idx && p->out && p->B > 0 && p->T > 0 && p->C > 0 && p->fill_cols >= p->C, "zs_add_rowvec: bad args");
+  ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_add_rowvec: bad dtype");
+  ZS_DISPATCH(p->dtype, add_rowvec_kernel, dim3(nblocks((int64_t)p->B * p->T * p->fill_cols, 4096)), dim3(NTE), stream, *p);
+  return zs_check_launch("zs_add_rowvec");
+}
+
+extern "C" int zs_emb_scatter(const ZsEmbScatter* p, void* stream) {
+  ZS_REQUIRE(p && p->emb_sum && p->idx && p->demb && p->B > 0 && p->n_rows > 0 && p->C > 0, "zs_emb_scatter: bad args");
+  hipLaunchKernelGGL(emb_scatter_kernel, dim3((p->C + 127) / 128, p->n_rows), dim3(128), 0, (hipStream_t)stream, *p);
+  return zs_check_launch("zs_emb_scatter");
+}
+
+extern "C" int zs_mbv_fwd(const ZsMbvFwd* p, void* stream) {
+  ZS_REQUIRE(p && p->logits && p->rows > 0 && p->E > 0 && p->tau > 0.f, "zs_mbv_fwd: bad args");
+  ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_mbv_fwd: bad dtype");
+  ZS_REQUIRE(p->noise_kind == 2 || p->noise, "zs_mbv_fwd: noise missing");
+  ZS_REQUIRE(p->bits || p->bits_f32, "zs_mbv_fwd: no output");
+  ZsMbvFwd q = *p;
+  if (!q.bits || q.bits_fill_cols < q.E) q.bits_fill_cols = q.E;
+  ZS_DISPATCH(p->dtype, mbv_fwd_kernel, dim3(nblocks(q.rows * q.bits_fill_cols)), dim3(NTE), stream, q);
+  return zs_check_launch("zs_mbv_fwd");
+}
+
+extern "C" int zs_mbv_bwd(const ZsMbvBwd* p, void* stream) {
+  ZS_REQUIRE(p && p->dbits && p->y0 && p->dlogits && p->rows > 0 && p->E > 0 && p->fill_cols >= 2 * p->E && p->fill_cols % 2 == 0,
+             "zs_mbv_bwd: bad args");
+  ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_mbv_bwd: bad dtype");
+  ZS_DISPATCH(p->dtype, mbv_bwd_kernel, dim3(nblocks(p->rows * (p->fill_cols / 2))), dim3(NTE), stream, *p);
+  return zs_check_launch("zs_mbv_bwd");
+}
+
+extern "C" int zs_l1_loss(const ZsL1Loss* p, void* stream) {
+  ZS_REQUIRE(p && p->x_dec && p->x && p->partial && p->loss_out && p->rows > 0 && p->F > 0, "zs_l1_loss: bad args");
+  ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_l1_loss: bad dtype");
+  ZsL1Loss q = *p;
+  if (!q.dlogits || q.fill_cols < q.F) q.fill_cols = q.F;
+  const unsigned nb = nblocks(q.rows * q.fill_cols, 1024);
+  ZS_DISPATCH(p->dtype, l1_stage1_kernel, dim3(nb), dim3(NTE), stream, q);
+  int rc = zs_check_launch("zs_l1_loss.stage1");
+  if (rc) return rc;
+  hipLaunchKernelGGL(l1_stage2_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)p->partial, (int)nb, p->loss_out,
+                     (double)p->rows * (double)p->F);
+  return zs_check_launch("zs_l1_loss.stage2");
+}
+
+extern "C" int zs_sqnorm(const float* g, int64_t n, double* partial, float* out_sq, void* stream) {
+  ZS_REQUIRE(g && partial && out_sq && n > 0, "zs_sqnorm: bad args");
+  const unsigned nb = nblocks(n, 1024);
+  hipLaunchKernelGGL(sqnorm_stage1_kernel, dim3(nb), dim3(NTE), 0, (hipStream_t)stream, g, n, partial);
+  int rc = zs_check_launch("zs_sqnorm.stage1");
+  if (rc) return rc;
+  hipLaunchKernelGGL(sqnorm_stage2_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)partial, (int)nb, out_sq);
+  return zs_check_launch("zs_sqnorm.stage2");
+}
+
+extern "C" int zs_adam_clip(const ZsAdam* p, void* stream) {
+  ZS_REQUIRE(p && p->p && p->g && p->m && p->v && p->n > 0, "zs_adam_clip: bad args");
+  ZS_REQUIRE(p->bc1 > 0.f && p->bc2 > 0.f, "zs_adam_clip: bias corrections");
+  hipLaunchKernelGGL(adam_kernel, dim3(nblocks(p->n, 4096)), dim3(NTE), 0, (hipStream_t)stream, *p);
+  return zs_check_launch("zs_adam_clip");
+}
+
+extern "C" int zs_softmax_ce(const ZsSoftmaxCE* p, void* stream) {
+  ZS_REQUIRE(p && p->logits && p->target && p->loss_out && p->B > 0 && p->n_class > 0, "zs_softmax_ce: bad args");
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *p);
+  return zs_check_launch("zs_softmax_ce");
+}

@@ -1,0 +1,522 @@
+// zs_gemm.hip -- MFMA implicit-GEMM Conv1d / Linear (forward + data gradient) and weight gradient.
+//
+// gfx950 design notes
+//  * 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each 64x64 = 2x2 MFMA 32x32 tiles,
+//    64 fp32 accumulators/lane).  K is consumed in 128-byte chunks per row (64 bf16 / 32 fp32).
+//  * Operand rows are whole channels-last activation rows, so the conv "im2col" is a per-row pointer
+//    computation (tap shift, reflect / zero padding, stride, transposed-conv validity) done by the
+//    loader threads only when the tap changes -- no padded copy of the activation is ever made
+//    (the reference does F.pad + conv, model/model.py:36-39).
+//  * Register staging (global_load_dwordx4 -> ds_write_b128), double-buffered LDS, one barrier per
+//    K chunk; loads for chunk k+1 are issued before the MFMAs of chunk k (issue-early/write-late).
+//  * LDS rows are padded to 144 B: the 16 rows a ds_read_b128 lane group touches fall on 16 distinct
+//    16-byte slots of the 256-byte bank row (9*r mod 16 is a bijection), so fragment reads are
+//    conflict free; one ds_read_b128 feeds one v_mfma_f32_32x32x16_bf16 (bf16) or four
+//    v_mfma_f32_32x32x2_f32 (exact fp32; lane h supplies k = 4h+q in step q on both operands).
+//  * Accumulator layout (32x32): col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); lanes run
+//    along the output channel, so each store instruction writes 32 consecutive channels of a row.
+//  * blockIdx -> tile map is XCD-aware (consecutive tiles of one M panel share an XCD's L2).
+#include "zs_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, NT = 256;
+constexpr int ROWB = 128;    // bytes of K per LDS row
+constexpr int PITCH = 144;   // LDS row pitch (bytes)
+constexpr int TILE_BYTES = BM * PITCH;
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// source row of output position t for tap j; ok=false -> the row contributes zeros
+__device__ __forceinline__ int conv_src_row(int gather, int pad_mode, int stride, int pad_left, int T_in, int t,
+                                            int j, bool& ok) {
+  if (gather == 0) {
+    int s = t * stride + j - pad_left;
+    if (pad_mode == ZS_PAD_REFLECT) s = zs_reflect(s, T_in);
+    ok = (s >= 0) && (s < T_in);
+    return s;
+  }
+  int s = t - j;
+  ok = false;
+  if (s < 0) return 0;
+  int q = s / stride;
+  ok = (q * stride == s) && (q < T_in);
+  return q;
+}
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(NT, 2) void gemm_conv_kernel(const ZsGemmConv p) {
+  constexpr int EPS = 16 / (int)sizeof(T);    // elements per 16-byte segment
+  constexpr int KC = ROWB / (int)sizeof(T);   // elements per K chunk
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sA = smem;                    // [2][TILE_BYTES]
+  unsigned char* sB = smem + 2 * TILE_BYTES;   // [2][TILE_BYTES]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g = blockIdx.z;
+  const T* __restrict__ A = (const T*)p.A + (int64_t)g * p.a_gstride;
+  const T* __restrict__ W = (const T*)p.W + (int64_t)g * p.w_gstride;
+  const int M = p.B * p.T_out;
+  const int ntn = (p.N + BN - 1) / BN;
+  const int ntm = (M + BM - 1) / BM;
+  const int wg = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
+
+  // ---- loader state: 4 rows x one 16-B segment per thread, for A and for W ----
+  const int seg = tid & 7, r0 = tid >> 3;
+  int rb[4], rt[4];            // sample / position of the 4 A rows (rb<0: row beyond M)
+  int64_t aoff[4];             // element offset of the current tap's source row (-1: zero row)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + r0 + 32 * i;
+    if (m < M) { rb[i] = m / p.T_out; rt[i] = m - rb[i] * p.T_out; } else { rb[i] = -1; rt[i] = 0; }
+  }
+  const int ktaps = p.taps, cin_pad = p.cin_pad;
+  int tap = (seg * EPS) / cin_pad;
+  int ci = seg * EPS - tap * cin_pad;
+  auto set_tap = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bool ok = false; int s = 0;
+      if (rb[i] >= 0 && tap < ktaps) s = conv_src_row(p.gather, p.pad_mode, p.stride, p.pad_left, p.T_in, rt[i], tap, ok);
+      aoff[i] = ok ? ((int64_t)rb[i] * p.a_batch_stride + (int64_t)s * p.lda) : (int64_t)-1;
+    }
+  };
+  set_tap();
+  const T* wrow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wrow[i] = W + (int64_t)(n0 + r0 + 32 * i) * p.ldw + seg * EPS;
+
+  const int nk = (int)(p.ldw / KC);
+  uint4 va[4], vb[4];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      va[i] = (aoff[i] >= 0) ? *reinterpret_cast<const uint4*>(A + aoff[i] + ci) : make_uint4(0, 0, 0, 0);
+      vb[i] = *reinterpret_cast<const uint4*>(wrow[i] + (int64_t)kt * KC);
+    }
+    ci += KC;                                  // advance this thread's K cursor to the next chunk
+    bool moved = false;
+    while (ci >= cin_pad) { ci -= cin_pad; ++tap; moved = true; }
+    if (moved) set_tap();
+  };
+  auto swrite = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<uint4*>(sA + buf * TILE_BYTES + (r0 + 32 * i) * PITCH + seg * 16) = va[i];
+      *reinterpret_cast<uint4*>(sB + buf * TILE_BYTES + (r0 + 32 * i) * PITCH + seg * 16) = vb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  gload(0);
+  swrite(0);
+  __syncthreads();
+  const int frow = lane & 31, fh = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const unsigned char* a_base = sA + buf * TILE_BYTES + (wm * 64 + frow) * PITCH + fh * 16;
+    const unsigned char* b_base = sB + buf * TILE_BYTES + (wn * 64 + frow) * PITCH + fh * 16;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      uint4 fa[2], fb[2];
+      fa[0] = *reinterpret_cast<const uint4*>(a_base + ks * 32);
+      fa[1] = *reinterpret_cast<const uint4*>(a_base + 32 * PITCH + ks * 32);
+      fb[0] = *reinterpret_cast<const uint4*>(b_base + ks * 32);
+      fb[1] = *reinterpret_cast<const uint4*>(b_base + 32 * PITCH + ks * 32);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) Mma<T>::run(fa[mi], fb[ni], acc[mi][ni]);
+    }
+    if (kt + 1 < nk) swrite(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  const bool need_b = (p.pre_vec != nullptr) || (p.vec2 != nullptr);
+  const int half = p.N >> 1;
+  float* outf = (float*)p.out + (p.out_f32 ? (int64_t)g * p.out_gstride : 0);
+  T* outt = (T*)p.out + (p.out_f32 ? 0 : (int64_t)g * p.out_gstride);
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int n = n0 + wn * 64 + ni * 32 + (lane & 31);
+    const bool nvalid = n < p.N;
+    const float bias = (p.bias != nullptr && nvalid) ? p.bias[(int64_t)g * p.bias_gstride + n] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= M) continue;
+        float v = 0.f;
+        int b = 0;
+        if (need_b) b = m / p.T_out;
+        if (nvalid) {
+          v = acc[mi][ni][r] + bias;
+          if (p.pre_vec) v += p.pre_vec[p.vec_idx[b] * p.pre_vec_ld + n];
+          if (p.act == ZS_ACT_LRELU) v = lrelu_f(v, p.slope);
+          else if (p.act == ZS_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+          else if (p.act == ZS_ACT_TANH) v = tanhf(v);
+          if (p.dact_src) v *= dlrelu_f(Elem<T>::ld((const T*)p.dact_src + (int64_t)m * p.dact_ld + n), p.slope);
+          if (p.add_src) {
+            v += p.add_f32 ? ((const float*)p.add_src)[(int64_t)m * p.add_ld + n]
+                           : Elem<T>::ld((const T*)p.add_src + (int64_t)m * p.add_ld + n);
+          }
+        }
+        if (p.out) {
+          int64_t orow = m; int ocol = n; bool st = n < p.out_cols;
+          if (p.store_mode == ZS_STORE_SPLIT2) {
+            const int hi = n >= half; orow = 2 * (int64_t)m + hi; ocol = n - hi * half; st = nvalid;
+          }
+          if (st) {
+            if (p.out_f32) outf[orow * p.ldc + ocol] = v; else Elem<T>::st(outt + orow * p.ldc + ocol, v);
+          }
+        }
+        if (p.out2) {
+          int64_t orow = m; int ocol = n; bool st = n < p.out2_cols;
+          if (p.store_mode2 == ZS_STORE_SPLIT2) {
+            const int hi = n >= half; orow = 2 * (int64_t)m + hi; ocol = n - hi * half; st = nvalid;
+          }
+          if (st) {
+            float v2 = v;
+            if (p.vec2 && nvalid) v2 += p.vec2[p.vec_idx[b] * p.vec2_ld + ocol];
+            Elem<T>::st((T*)p.out2 + orow * p.ldc2 + ocol, v2);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient: slab[split][co][tap][ci] = sum_{m in split} dY[m][co] * X[row(m,tap)][ci]
+// Both operands are K(=row)-strided in memory.  fp32 fragments are natural (lane = channel, one
+// ds_read_b32 per MFMA operand); bf16 fragments gather 8 rows per lane with ds_read_u16.
+// ------------------------------------------------------------------------------------------------
+constexpr int WK = 32;   // rows (K) per chunk
+
+template <typename T> struct WFrag;
+template <> struct WFrag<float> {
+  static constexpr int PITCHW = 128 * 4 + 16;
+  // chunk of 32 rows -> 16 steps of v_mfma_f32_32x32x2_f32 (k = 2*step + lane>>5)
+  static __device__ __forceinline__ void chunk(const unsigned char* sY, const unsigned char* sX, int wm, int wn, int lane,
+                                               f32x16 (&acc)[2][2]) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *reinterpret_cast<const float*>(sY + (2 * st + h) * PITCHW + (wm * 64 + i * 32 + r) * 4);
+        b[i] = *reinterpret_cast<const float*>(sX + (2 * st + h) * PITCHW + (wn * 64 + i * 32 + r) * 4);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+  }
+};
+template <> struct WFrag<bf16_t> {
+  static constexpr int PITCHW = 128 * 2 + 16;
+  // chunk of 32 rows -> 2 steps of v_mfma_f32_32x32x16_bf16 (k = 16*step + 8*(lane>>5) + j)
+  static __device__ __forceinline__ void chunk(const unsigned char* sY, const unsigned char* sX, int wm, int wn, int lane,
+                                               f32x16 (&acc)[2][2]) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      bf16x8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = 16 * st + 8 * h + j;
+          a[i][j] = __builtin_bit_cast(__bf16, *reinterpret_cast<const bf16_t*>(sY + k * PITCHW + (wm * 64 + i * 32 + r) * 2));
+          b[i][j] = __builtin_bit_cast(__bf16, *reinterpret_cast<const bf16_t*>(sX + k * PITCHW + (wn * 64 + i * 32 + r) * 2));
+        }
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(NT, 2) void gemm_wgrad_kernel(const ZsGemmWgrad p, int ci_tiles, int rows_per_split,
+                                                          int cout_r, int cin_r) {
+  constexpr int EPS = 16 / (int)sizeof(T);
+  constexpr int SPR = 128 / EPS;               // 16-B segments per 128-element row
+  constexpr int LPT = (WK * SPR) / NT;         // loads per thread per operand (2 bf16, 4 fp32)
+  constexpr int PITCHW = WFrag<T>::PITCHW;
+  constexpr int TILEW = WK * PITCHW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sY = smem;                    // [2][TILEW]
+  unsigned char* sX = smem + 2 * TILEW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int per_co = p.taps * ci_tiles;
+  const int cot = blockIdx.x / per_co;
+  const int rem = blockIdx.x - cot * per_co;
+  const int tap = rem / ci_tiles, cit = rem - tap * ci_tiles;
+  const int co0 = cot * 128, ci0 = cit * 128;
+  const int M = p.B * p.T_out;
+  const int mbeg = blockIdx.y * rows_per_split;
+  const int mend = min(M, mbeg + rows_per_split);
+  const T* __restrict__ dY = (const T*)p.dY;
+  const T* __restrict__ X = (const T*)p.X;
+
+  int lrow[LPT], lseg[LPT], lb[LPT], lt[LPT];
+#pragma unroll
+  for (int i = 0; i < LPT; ++i) {
+    const int idx = tid + NT * i;
+    lrow[i] = idx / SPR; lseg[i] = idx - lrow[i] * SPR;
+    const int m = mbeg + lrow[i];
+    lb[i] = m / p.T_out; lt[i] = m - lb[i] * p.T_out;
+  }
+  uint4 vy[LPT], vx[LPT];
+  // bias gradient: the (tap 0, ci-tile 0) workgroup of each co-tile also sums its dY tile over rows
+  const bool do_bias = (p.db != nullptr) && tap == 0 && cit == 0;
+  float bsum[LPT][EPS];
+#pragma unroll
+  for (int i = 0; i < LPT; ++i)
+#pragma unroll
+    for (int e = 0; e < EPS; ++e) bsum[i][e] = 0.f;
+  auto gload = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+      const int m = mb + lrow[i];
+      const int cy = co0 + lseg[i] * EPS, cx = ci0 + lseg[i] * EPS;
+      vy[i] = make_uint4(0, 0, 0, 0); vx[i] = make_uint4(0, 0, 0, 0);
+      if (m < mend) {
+        if (cy < p.y_cols) vy[i] = *reinterpret_cast<const uint4*>(dY + (int64_t)m * p.ldy + cy);
+        bool ok; const int s = conv_src_row(0, p.pad_mode, p.stride, p.pad_left, p.T_in, lt[i], tap, ok);
+        if (ok && cx < p.x_cols)
+          vx[i] = *reinterpret_cast<const uint4*>(X + (int64_t)lb[i] * p.x_batch_stride + (int64_t)s * p.ldx + cx);
+      }
+      lt[i] += WK;                               // next chunk: m += 32
+      while (lt[i] >= p.T_out) { lt[i] -= p.T_out; ++lb[i]; }
+    }
+  };
+  auto swrite = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+      *reinterpret_cast<uint4*>(sY + buf * TILEW + lrow[i] * PITCHW + lseg[i] * 16) = vy[i];
+      *reinterpret_cast<uint4*>(sX + buf * TILEW + lrow[i] * PITCHW + lseg[i] * 16) = vx[i];
+      if (do_bias) {                                             // data has landed here anyway (wave-uniform branch)
+        const uint32_t w4[4] = {vy[i].x, vy[i].y, vy[i].z, vy[i].w};
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bsum[i][e] += __uint_as_float(w4[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            bsum[i][2 * e] += __uint_as_float(w4[e] << 16);
+            bsum[i][2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u);
+          }
+        }
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nchunks = (mend - mbeg + WK - 1) / WK;
+  if (nchunks > 0) {
+    gload(mbeg);
+    swrite(0);
+  }
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) gload(mbeg + (c + 1) * WK);
+    WFrag<T>::chunk(sY + buf * TILEW, sX + buf * TILEW, wm, wn, lane, acc);
+    if (c + 1 < nchunks) swrite(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (do_bias) {
+    // LDS is free now (the K loop ended with a barrier): red[32 rows][128 cols] fp32 = 16 KiB
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < LPT; ++i)
+#pragma unroll
+      for (int e = 0; e < EPS; ++e) red[lrow[i] * 128 + lseg[i] * EPS + e] = bsum[i][e];
+    __syncthreads();
+    if (tid < 128) {
+      float t = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < WK; ++r) t += red[r * 128 + tid];
+      float* bslab = (float*)p.workspace + (int64_t)gridDim.y * cout_r * p.taps * cin_r + (int64_t)blockIdx.y * cout_r;
+      bslab[co0 + tid] = t;
+    }
+  }
+  // slab[split][co][tap][ci], co < cout_r, ci < cin_r (full tiles: no guards needed)
+  float* slab = (float*)p.workspace + (int64_t)blockIdx.y * cout_r * p.taps * cin_r;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int ci = ci0 + wn * 64 + ni * 32 + (lane & 31);
+        slab[((int64_t)co * p.taps + tap) * cin_r + ci] = acc[mi][ni][r];
+      }
+}
+
+__global__ void wgrad_reduce_kernel(const ZsGemmWgrad p, int splits, int cout_r, int cin_r) {
+  const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;
+  const int co = blockIdx.z;
+  if (ci >= p.Cin) return;
+  const int half = p.Cout >> 1;
+  const int cop = p.co_split2 ? ((co & 1) * half + (co >> 1)) : co;
+  const float* ws = (const float*)p.workspace + ((int64_t)cop * p.taps + j) * cin_r + ci;
+  const int64_t sstride = (int64_t)cout_r * p.taps * cin_r;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += ws[k * sstride];
+  float* d = p.dW + (int64_t)co * p.so + (int64_t)ci * p.si + (int64_t)j * p.sj;
+  *d = p.accumulate ? (*d + s) : s;
+  if (p.db != nullptr && ci == 0 && j == 0) {
+    const float* bs = (const float*)p.workspace + (int64_t)splits * sstride + cop;
+    float t = 0.f;
+    for (int k = 0; k < splits; ++k) t += bs[(int64_t)k * cout_r];
+    p.db[co] = p.accumulate ? (p.db[co] + t) : t;
+  }
+}
+
+int pick_splits(const ZsGemmWgrad* p) {
+  if (p->splits > 0) return p->splits;
+  const int64_t M = (int64_t)p->B * p->T_out;
+  const int64_t tiles = (int64_t)((p->Cout + 127) / 128) * p->taps * ((p->Cin + 127) / 128);
+  int64_t s = (768 + tiles - 1) / tiles;
+  int64_t maxs = (M + 255) / 256;
+  if (s > maxs) s = maxs;
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host entry points
+// ------------------------------------------------------------------------------------------------
+extern "C" int zs_gemm_conv(const ZsGemmConv* p, void* stream) {
+  ZS_REQUIRE(p && p->A && p->W && (p->out || p->out2), "zs_gemm_conv: null operand");
+  ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_gemm_conv: bad dtype %d", p->dtype);
+  const int es = p->dtype == ZS_F32 ? 4 : 2;
+  const int kc = 128 / es;
+  ZS_REQUIRE(p->B > 0 && p->T_in > 0 && p->T_out > 0 && p->N > 0 && p->taps > 0 && p->stride > 0, "zs_gemm_conv: bad sizes");
+  ZS_REQUIRE(p->cin_pad > 0 && p->cin_pad % 32 == 0, "zs_gemm_conv: cin_pad %d must be a multiple of 32", p->cin_pad);
+  ZS_REQUIRE(p->ldw % kc == 0 && p->ldw >= (int64_t)p->taps * p->cin_pad, "zs_gemm_conv: ldw %lld not a padded multiple of %d",
+             (long long)p->ldw, kc);
+  ZS_REQUIRE(p->n_pad % 128 == 0 && p->n_pad >= p->N, "zs_gemm_conv: n_pad %d must be a multiple of 128 >= N %d", p->n_pad, p->N);
+  ZS_REQUIRE(aligned16(p->A) && aligned16(p->W) && (p->lda * es) % 16 == 0 && (p->a_batch_stride * es) % 16 == 0 &&
+                 (p->a_gstride * es) % 16 == 0 && (p->w_gstride * es) % 16 == 0,
+             "zs_gemm_conv: operands must be 16-byte aligned (A=%p lda=%lld)", p->A, (long long)p->lda);
+  if (p->gather == 0 && p->pad_mode == ZS_PAD_REFLECT) {
+    const int pad_r = (p->T_out - 1) * p->stride + p->taps - 1 - p->pad_left - (p->T_in - 1);
+    ZS_REQUIRE(p->pad_left < p->T_in && pad_r < p->T_in,
+               "zs_gemm_conv: Padding size should be less than the corresponding input dimension (pad %d/%d, T %d)",
+               p->pad_left, pad_r, p->T_in);
+  }
+  if (p->store_mode == ZS_STORE_SPLIT2 || (p->out2 && p->store_mode2 == ZS_STORE_SPLIT2))
+    ZS_REQUIRE(p->N % 2 == 0, "zs_gemm_conv: SPLIT2 needs even N");
+  ZS_REQUIRE(!(p->pre_vec || p->vec2) || p->vec_idx, "zs_gemm_conv: vec_idx missing");
+  const int groups = p->groups > 0 ? p->groups : 1;
+  const int64_t M = (int64_t)p->B * p->T_out;
+  const int64_t tiles = ((M + BM - 1) / BM) * ((p->N + BN - 1) / BN);
+  ZS_REQUIRE(tiles < (1ll << 31), "zs_gemm_conv: grid too large");
+  dim3 grid((unsigned)tiles, 1, (unsigned)groups);
+  const size_t lds = 4 * TILE_BYTES;
+  hipStream_t s = (hipStream_t)stream;
+  if (p->dtype == ZS_F32) hipLaunchKernelGGL(gemm_conv_kernel<float>, grid, dim3(NT), lds, s, *p);
+  else hipLaunchKernelGGL(gemm_conv_kernel<bf16_t>, grid, dim3(NT), lds, s, *p);
+  return zs_check_launch("zs_gemm_conv");
+}
+
+extern "C" size_t zs_gemm_wgrad_workspace_bytes(const ZsGemmWgrad* p) {
+  if (!p) return 0;
+  const int64_t cout_r = (int64_t)((p->Cout + 127) / 128) * 128, cin_r = (int64_t)((p->Cin + 127) / 128) * 128;
+  return (size_t)pick_splits(p) * (cout_r * p->taps * cin_r + cout_r) * sizeof(float);
+}
+
+extern "C" int zs_gemm_wgrad(const ZsGemmWgrad* p, void* stream) {
+  ZS_REQUIRE(p && p->dY && p->X && p->dW && p->workspace, "zs_gemm_wgrad: null operand");
+  ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_gemm_wgrad: bad dtype");
+  const int es = p->dtype == ZS_F32 ? 4 : 2;
+  ZS_REQUIRE(p->B > 0 && p->T_in > 0 && p->T_out > 0 && p->Cout > 0 && p->Cin > 0 && p->taps > 0 && p->stride > 0,
+             "zs_gemm_wgrad: bad sizes");
+  ZS_REQUIRE(aligned16(p->dY) && aligned16(p->X) && (p->ldy * es) % 16 == 0 && (p->ldx * es) % 16 == 0 &&
+                 (p->x_batch_stride * es) % 16 == 0 && (p->y_cols * es) % 16 == 0 && (p->x_cols * es) % 16 == 0,
+             "zs_gemm_wgrad: operands must be 16-byte aligned");
+  ZS_REQUIRE(p->y_cols <= p->ldy && p->x_cols <= p->ldx && p->Cout <= p->y_cols && p->Cin <= p->x_cols, "zs_gemm_wgrad: column bounds");
+  ZS_REQUIRE(!p->co_split2 || p->Cout % 2 == 0, "zs_gemm_wgrad: SPLIT2 needs even Cout");
+  const int splits = pick_splits(p);
+  const int co_tiles = (p->Cout + 127) / 128, ci_tiles = (p->Cin + 127) / 128;
+  const int cout_r = co_tiles * 128, cin_r = ci_tiles * 128;
+  const size_t need = (size_t)splits * ((size_t)cout_r * p->taps * cin_r + cout_r) * sizeof(float);
+  if (p->workspace_bytes < need) {
+    zs_set_error("zs_gemm_wgrad: workspace %zu < %zu bytes", p->workspace_bytes, need);
+    return ZS_EWORKSPACE;
+  }
+  const int64_t M = (int64_t)p->B * p->T_out;
+  int rows_per_split = (int)((M + splits - 1) / splits);
+  rows_per_split = ((rows_per_split + WK - 1) / WK) * WK;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)(co_tiles * p->taps * ci_tiles), (unsigned)splits, 1);
+  if (p->dtype == ZS_F32) {
+    const size_t lds = 4 * WK * WFrag<float>::PITCHW;
+    hipLaunchKernelGGL(gemm_wgrad_kernel<float>, grid, dim3(NT), lds, s, *p, ci_tiles, rows_per_split, cout_r, cin_r);
+  } else {
+    const size_t lds = 4 * WK * WFrag<bf16_t>::PITCHW;
+    hipLaunchKernelGGL(gemm_wgrad_kernel<bf16_t>, grid, dim3(NT), lds, s, *p, ci_tiles, rows_per_split, cout_r, cin_r);
+  }
+  int rc = zs_check_launch("zs_gemm_wgrad");
+  if (rc) return rc;
+  dim3 rgrid((unsigned)((p->Cin + 127) / 128), (unsigned)p->taps, (unsigned)p->Cout);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(128), 0, s, *p, splits, cout_r, cin_r);
+  return zs_check_launch("zs_gemm_wgrad.reduce");
+}

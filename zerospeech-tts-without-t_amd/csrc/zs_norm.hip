@@ -1,0 +1,328 @@
+// zs_norm.hip -- InstanceNorm1d (+dropout +residual) forward/backward and the backward-path
+// "gradient combine" kernel.  All three share one decomposition of a channels-last [B,T,C] tensor:
+// a 256-thread workgroup owns (sample b, 64 channels); thread (cg = tid&7, rg = tid>>3) owns
+// channels 8cg..8cg+7 (one 16-byte access for bf16, two for fp32 -> 8 lanes cover one full 128-byte
+// line of a row) of rows t = rg + 32*i.  The per-(b,c) reduction over T happens across the 32 row
+// groups through LDS; values stay in registers between the passes (T <= 256 => <= 8 rows/thread), so
+// each activation is read from HBM exactly once.  These kernels are HBM-bound.
+#include "zs_common.h"
+
+namespace {
+
+constexpr int NTN = 256, CHUNK = 64, RG = 32, RPT = 8;   // threads, channels/WG, row groups, rows/thread
+
+// sum the per-thread partial p[8] of channel group cg across the 32 row groups; result broadcast.
+__device__ __forceinline__ void colreduce(float (&pv)[8], float* red, float* tot, int cg, int rg, int tid) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[rg * CHUNK + cg * 8 + k] = pv[k];
+  __syncthreads();
+  if (tid < CHUNK) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < RG; ++r) s += red[r * CHUNK + tid];
+    tot[tid] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) pv[k] = tot[cg * 8 + k];
+  __syncthreads();
+}
+
+__device__ __forceinline__ float keep_scale(const uint8_t* mask, int64_t mask_ld, float p, uint64_t seed, uint32_t sid,
+                                            int64_t row, int c, int C, float inv_keep) {
+  if (p <= 0.f) return 1.f;
+  bool keep;
+  if (mask) keep = (c < mask_ld) ? (mask[row * mask_ld + c] != 0) : true;
+  else keep = zs_keep(seed, sid, (uint64_t)row * (uint64_t)C + (uint64_t)c, p);
+  return keep ? inv_keep : 0.f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTN) void instnorm_fwd_kernel(const ZsInstNormFwd p) {
+  __shared__ float red[RG * CHUNK];
+  __shared__ float tot[CHUNK];
+  const int tid = threadIdx.x, cg = tid & 7, rg = tid >> 3;
+  const int b = blockIdx.y, c0 = blockIdx.x * CHUNK + cg * 8;
+  const bool cvalid = c0 < p.C;
+  const T* x = (const T*)p.x;
+  float v[RPT][8];
+  float s[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s[k] = 0.f;
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int t = rg + RG * i;
+    if (cvalid && t < p.T) {
+      load8<T>(x + ((int64_t)b * p.T + t) * p.ldx + c0, v[i]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] += v[i][k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[i][k] = 0.f;
+    }
+  }
+  colreduce(s, red, tot, cg, rg, tid);
+  float mean[8], q[8];
+  const float invT = 1.f / (float)p.T;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { mean[k] = s[k] * invT; q[k] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int t = rg + RG * i;
+    if (t < p.T) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mean[k]; q[k] += d * d; }
+    }
+  }
+  colreduce(q, red, tot, cg, rg, tid);
+  float rstd[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) rstd[k] = 1.f / sqrtf(q[k] * invT + p.eps);
+  if (!cvalid) return;
+  if (p.mean && rg == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { p.mean[(int64_t)b * p.C + c0 + k] = mean[k]; p.rstd[(int64_t)b * p.C + c0 + k] = rstd[k]; }
+  }
+  const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+  float e2[8];
+  if (p.out2) {
+    const int64_t vi = p.idx ? p.idx[b] : 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e2[k] = (p.vec2 && (c0 + k) < p.vec2_cols) ? p.vec2[vi * p.vec2_ld + c0 + k] : 0.f;
+  }
+  const T* res = (const T*)p.res;
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int t = rg + RG * i;
+    if (t >= p.T) continue;
+    const int64_t row = (int64_t)b * p.T + t;
+    float o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      o[k] = (v[i][k] - mean[k]) * rstd[k];
+      o[k] *= keep_scale(p.mask, p.mask_ld, p.drop_p, p.seed, p.stream_id, row, c0 + k, p.C, inv_keep);
+    }
+    if (p.res_mode == ZS_RES_IDENTITY) {
+      float r[8]; load8<T>(res + row * p.ldres + c0, r);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] += r[k];
+    } else if (p.res_mode == ZS_RES_UPSAMPLE2) {
+      float r[8]; load8<T>(res + ((int64_t)b * p.T_res + (t >> 1)) * p.ldres + c0, r);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] += r[k];
+    } else if (p.res_mode == ZS_RES_AVGPOOL2) {
+      // F.pad(x, (0, T%2), reflect|constant) + avg_pool1d(2)   (model/model.py:424-425)
+      float r0[8], r1[8];
+      load8<T>(res + ((int64_t)b * p.T_res + 2 * t) * p.ldres + c0, r0);
+      int t1 = 2 * t + 1; bool have = true;
+      if (t1 >= p.T_res) { if (p.res_pad_mode == ZS_PAD_REFLECT) t1 = p.T_res - 2; else have = false; }
+      if (have) load8<T>(res + ((int64_t)b * p.T_res + t1) * p.ldres + c0, r1);
+      else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r1[k] = 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] += (r0[k] + r1[k]) * 0.5f;
+    }
+    store8<T>((T*)p.out + row * p.ldo + c0, o);
+    if (p.out2) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] += e2[k];
+      store8<T>((T*)p.out2 + row * p.ldo2 + c0, o);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTN) void instnorm_bwd_kernel(const ZsInstNormBwd p) {
+  __shared__ float red[RG * CHUNK];
+  __shared__ float tot[CHUNK];
+  const int tid = threadIdx.x, cg = tid & 7, rg = tid >> 3;
+  const int b = blockIdx.y, c0 = blockIdx.x * CHUNK + cg * 8;
+  const bool cvalid = c0 < p.C;
+  float mean[8], rstd[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    mean[k] = cvalid ? p.mean[(int64_t)b * p.C + c0 + k] : 0.f;
+    rstd[k] = cvalid ? p.rstd[(int64_t)b * p.C + c0 + k] : 0.f;
+  }
+  const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+  float g[RPT][8], xv[RPT][8];
+  float sg[8], sgx[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { sg[k] = 0.f; sgx[k] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int t = rg + RG * i;
+    if (cvalid && t < p.T) {
+      const int64_t row = (int64_t)b * p.T + t;
+      load8<T>((const T*)p.dout + row * p.ldd + c0, g[i]);
+      load8<T>((const T*)p.x + row * p.ldx + c0, xv[i]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        g[i][k] *= keep_scale(p.mask, p.mask_ld, p.drop_p, p.seed, p.stream_id, row, c0 + k, p.C, inv_keep);
+        const float xh = (xv[i][k] - mean[k]) * rstd[k];
+        sg[k] += g[i][k]; sgx[k] += g[i][k] * xh;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { g[i][k] = 0.f; xv[i][k] = 0.f; }
+    }
+  }
+  colreduce(sg, red, tot, cg, rg, tid);
+  colreduce(sgx, red, tot, cg, rg, tid);
+  if (!cvalid) return;
+  const float invT = 1.f / (float)p.T;
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int t = rg + RG * i;
+    if (t >= p.T) continue;
+    const int64_t row = (int64_t)b * p.T + t;
+    float o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float xh = (xv[i][k] - mean[k]) * rstd[k];
+      const float dx = rstd[k] * (g[i][k] - sg[k] * invT - xh * (sgx[k] * invT));
+      o[k] = dx * dlrelu_f(xv[i][k], p.slope);
+    }
+    store8<T>((T*)p.dz + row * p.ldz + c0, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTN) void grad_combine_kernel(const ZsGradCombine p) {
+  __shared__ float red[RG * CHUNK];
+  __shared__ float tot[CHUNK];
+  const int tid = threadIdx.x, cg = tid & 7, rg = tid >> 3;
+  const int b = blockIdx.y, c0 = blockIdx.x * CHUNK + cg * 8;
+  const bool cvalid = c0 < p.C;
+  const int Tp = p.T + p.pad_left + p.pad_right;
+  const T* gp = (const T*)p.gp;
+  float v[RPT][8];
+  float s[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s[k] = 0.f;
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int t = rg + RG * i;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[i][k] = 0.f;
+    if (cvalid && t < p.T) {
+      const T* base = gp + (int64_t)b * Tp * p.ldg + c0;
+      load8<T>(base + (int64_t)(t + p.pad_left) * p.ldg, v[i]);
+      if (p.pad_mode == ZS_PAD_REFLECT) {
+        if (t >= 1 && t <= p.pad_left) {                       // left reflection partner
+          float r[8]; load8<T>(base + (int64_t)(p.pad_left - t) * p.ldg, r);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[i][k] += r[k];
+        }
+        if (t <= p.T - 2 && t >= p.T - 1 - p.pad_right) {      // right reflection partner
+          float r[8]; load8<T>(base + (int64_t)(p.pad_left + 2 * (p.T - 1) - t) * p.ldg, r);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[i][k] += r[k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] += v[i][k];
+    }
+  }
+  if (p.emb_sum) {                                             // uniform branch
+    colreduce(s, red, tot, cg, rg, tid);
+    if (cvalid && rg == 0) {                                   // this workgroup owns (b, these channels): plain RMW
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (c0 + k < p.emb_cols) p.emb_sum[(int64_t)b * p.emb_ld + c0 + k] += s[k];
+    }
+  }
+  if (!cvalid || p.out == nullptr) return;
+  const T* res = (const T*)p.res;
+  const T* da = (const T*)p.dact_src;
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int t = rg + RG * i;
+    if (t >= p.T) continue;
+    float o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = v[i][k];
+    if (p.res_mode == ZS_RES_IDENTITY) {
+      float r[8]; load8<T>(res + ((int64_t)b * p.T + t) * p.ldres + c0, r);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] += r[k];
+    } else if (p.res_mode == ZS_RES_AVGPOOL2) {                // backward of avg_pool1d(2), even T
+      float r[8]; load8<T>(res + ((int64_t)b * (p.T >> 1) + (t >> 1)) * p.ldres + c0, r);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] += 0.5f * r[k];
+    } else if (p.res_mode == ZS_RES_UPSAMPLE2) {               // backward of nearest x2
+      float r0[8], r1[8];
+      load8<T>(res + ((int64_t)b * 2 * p.T + 2 * t) * p.ldres + c0, r0);
+      load8<T>(res + ((int64_t)b * 2 * p.T + 2 * t + 1) * p.ldres + c0, r1);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] += r0[k] + r1[k];
+    }
+    int64_t orow = (int64_t)b * p.T + t; int ocol = c0;
+    if (p.unshuffle) { orow = (int64_t)b * (p.T >> 1) + (t >> 1); ocol = (t & 1) * p.C + c0; }
+    if (da) {
+      float y[8]; load8<T>(da + orow * p.dact_ld + ocol, y);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] *= dlrelu_f(y[k], p.slope);
+    }
+    store8<T>((T*)p.out + orow * p.ldo + ocol, o);
+  }
+}
+
+bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int zs_instnorm_fwd(const ZsInstNormFwd* p, void* stream) {
+  ZS_REQUIRE(p && p->x && p->out, "zs_instnorm_fwd: null operand");
+  ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_instnorm_fwd: bad dtype");
+  const int es = p->dtype == ZS_F32 ? 4 : 2;
+  ZS_REQUIRE(p->B > 0 && p->T > 0 && p->T <= RG * RPT && p->C > 0 && p->C % 8 == 0, "zs_instnorm_fwd: need 0<T<=256 (T=%d), C%%8==0 (C=%d)", p->T, p->C);
+  ZS_REQUIRE(al16(p->x) && al16(p->out) && (p->ldx * es) % 16 == 0 && (p->ldo * es) % 16 == 0, "zs_instnorm_fwd: alignment");
+  ZS_REQUIRE(!p->out2 || (al16(p->out2) && (p->ldo2 * es) % 16 == 0 && (!p->vec2 || p->idx)), "zs_instnorm_fwd: out2");
+  ZS_REQUIRE((p->mean == nullptr) == (p->rstd == nullptr), "zs_instnorm_fwd: mean/rstd");
+  if (p->res_mode != ZS_RES_NONE) {
+    ZS_REQUIRE(p->res && al16(p->res) && (p->ldres * es) % 16 == 0, "zs_instnorm_fwd: residual");
+    if (p->res_mode == ZS_RES_UPSAMPLE2) ZS_REQUIRE(p->T_res * 2 == p->T, "zs_instnorm_fwd: upsample T_res %d vs T %d", p->T_res, p->T);
+    if (p->res_mode == ZS_RES_AVGPOOL2) ZS_REQUIRE((p->T_res + 1) / 2 == p->T && p->T_res >= 2, "zs_instnorm_fwd: avgpool T_res %d vs T %d", p->T_res, p->T);
+  }
+  ZS_REQUIRE(p->drop_p >= 0.f && p->drop_p < 1.f, "zs_instnorm_fwd: drop_p");
+  dim3 grid((p->C + CHUNK - 1) / CHUNK, p->B);
+  if (p->dtype == ZS_F32) hipLaunchKernelGGL(instnorm_fwd_kernel<float>, grid, dim3(NTN), 0, (hipStream_t)stream, *p);
+  else hipLaunchKernelGGL(instnorm_fwd_kernel<bf16_t>, grid, dim3(NTN), 0, (hipStream_t)stream, *p);
+  return zs_check_launch("zs_instnorm_fwd");
+}
+
+extern "C" int zs_instnorm_bwd(const ZsInstNormBwd* p, void* stream) {
+  ZS_REQUIRE(p && p->dout && p->x && p->mean && p->rstd && p->dz, "zs_instnorm_bwd: null operand");
+  ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_instnorm_bwd: bad dtype");
+  const int es = p->dtype == ZS_F32 ? 4 : 2;
+  ZS_REQUIRE(p->B > 0 && p->T > 0 && p->T <= RG * RPT && p->C > 0 && p->C % 8 == 0, "zs_instnorm_bwd: sizes");
+  ZS_REQUIRE(al16(p->dout) && al16(p->x) && al16(p->dz) && (p->ldd * es) % 16 == 0 && (p->ldx * es) % 16 == 0 && (p->ldz * es) % 16 == 0,
+             "zs_instnorm_bwd: alignment");
+  dim3 grid((p->C + CHUNK - 1) / CHUNK, p->B);
+  if (p->dtype == ZS_F32) hipLaunchKernelGGL(instnorm_bwd_kernel<float>, grid, dim3(NTN), 0, (hipStream_t)stream, *p);
+  else hipLaunchKernelGGL(instnorm_bwd_kernel<bf16_t>, grid, dim3(NTN), 0, (hipStream_t)stream, *p);
+  return zs_check_launch("zs_instnorm_bwd");
+}
+
+extern "C" int zs_grad_combine(const ZsGradCombine* p, void* stream) {
+  ZS_REQUIRE(p && p->gp && (p->out || p->emb_sum), "zs_grad_combine: null operand");
+  ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_grad_combine: bad dtype");
+  const int es = p->dtype == ZS_F32 ? 4 : 2;
+  ZS_REQUIRE(p->B > 0 && p->T > 0 && p->T <= RG * RPT && p->C > 0 && p->C % 8 == 0, "zs_grad_combine: sizes T=%d C=%d", p->T, p->C);
+  ZS_REQUIRE(p->pad_left >= 0 && p->pad_right >= 0 && (p->pad_mode != ZS_PAD_REFLECT || (p->pad_left < p->T && p->pad_right < p->T)),
+             "zs_grad_combine: pads");
+  ZS_REQUIRE(al16(p->gp) && (p->ldg * es) % 16 == 0 && (!p->out || (al16(p->out) && (p->ldo * es) % 16 == 0)), "zs_grad_combine: alignment");
+  if (p->res_mode != ZS_RES_NONE) {
+    ZS_REQUIRE(p->res && al16(p->res) && (p->ldres * es) % 16 == 0, "zs_grad_combine: residual");
+    ZS_REQUIRE(p->res_mode != ZS_RES_AVGPOOL2 || p->T % 2 == 0, "zs_grad_combine: avgpool backward needs even T");
+  }
+  ZS_REQUIRE(!p->unshuffle || (p->T % 2 == 0 && (p->C * es) % 16 == 0), "zs_grad_combine: unshuffle");
+  ZS_REQUIRE(!p->dact_src || (al16(p->dact_src) && (p->dact_ld * es) % 16 == 0), "zs_grad_combine: dact");
+  dim3 grid((p->C + CHUNK - 1) / CHUNK, p->B);
+  if (p->dtype == ZS_F32) hipLaunchKernelGGL(grad_combine_kernel<float>, grid, dim3(NTN), 0, (hipStream_t)stream, *p);
+  else hipLaunchKernelGGL(grad_combine_kernel<bf16_t>, grid, dim3(NTN), 0, (hipStream_t)stream, *p);
+  return zs_check_launch("zs_grad_combine");
+}

@@ -1,0 +1,78 @@
+"""Data surface of the reference (dataloader.py:22-78): `DataLoader(dataset, batch_size)` whose
+`next()` returns `(LongTensor[B], FloatTensor[B, seg_len, 513])` with the reference's sliding-index /
+wrap rule, `Dataset` over the preprocessed HDF5 + JSON index, and a `SyntheticDataset` of the same item
+shape (no dataset ships with the reference; h5py is optional)."""
+import json
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+
+class DataLoader(object):
+    def __init__(self, dataset, batch_size=16):
+        self.dataset = dataset
+        self.n_elements = len(self.dataset[0])
+        self.batch_size = batch_size
+        self.index = 0
+
+    def _fetch(self, size):
+        samples = [self.dataset[self.index + i] for i in range(size)]
+        batch = [[s for s in sample] for sample in zip(*samples)]
+        batch_tensor = [torch.from_numpy(np.array(data)) for data in batch]
+        if self.index + 2 * self.batch_size >= len(self.dataset):      # dataloader.py:48-51 wrap rule
+            self.index = 0
+        else:
+            self.index += self.batch_size
+        return tuple(batch_tensor)
+
+    def all(self, size=1000):
+        return self._fetch(size)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return self._fetch(self.batch_size)
+
+
+class Dataset(torch.utils.data.Dataset):
+    """HDF5-backed segments, dataloader.py:56-78 (layout `{dset}/{speaker}/{utt}/lin|mel`)."""
+
+    def __init__(self, h5_path, index_path, dset='train', seg_len=64, load_mel=False):
+        try:
+            import h5py
+        except ImportError as e:                         # not installed in the build image
+            raise ImportError('zs_amd.dataloader.Dataset needs h5py to read %s' % h5_path) from e
+        self.dataset = h5py.File(h5_path, 'r')
+        with open(index_path) as f_index:
+            self.indexes = json.load(f_index)
+        self.indexer = namedtuple('index', ['speaker', 'i', 't'])
+        self.seg_len, self.dset, self.load_mel = seg_len, dset, load_mel
+
+    def __getitem__(self, i):
+        index = self.indexer(**self.indexes[i])
+        i, t = index.i, index.t
+        data = [index.speaker, self.dataset['%s/%s/lin' % (self.dset, i)][t:t + self.seg_len]]
+        if self.load_mel:
+            data.append(self.dataset['%s/%s/mel' % (self.dset, i)][t:t + self.seg_len])
+        return tuple(data)
+
+    def __len__(self):
+        return len(self.indexes)
+
+
+class SyntheticDataset(object):
+    """n segments of U[1e-8,1) 'lin' spectrogram frames (the value range preprocess.py:247-252 produces)
+    with random speaker ids; same item contract as Dataset.__getitem__."""
+
+    def __init__(self, n_items, seg_len=128, n_bins=513, n_speakers=102, seed=0, rank=0):
+        rng = np.random.RandomState(seed * 1000003 + rank)
+        self.spk = rng.randint(0, n_speakers, size=n_items).astype(np.int64)
+        self.lin = np.clip(rng.rand(n_items, seg_len, n_bins).astype(np.float32), 1e-8, 1.0)
+
+    def __getitem__(self, i):
+        return (self.spk[i], self.lin[i])
+
+    def __len__(self):
+        return len(self.spk)

@@ -1,0 +1,380 @@
+"""Forward / backward schedules of the autoencoder on the HIP kernels (channels-last, explicit tape).
+
+EncoderEngine  <->  Encoder.forward          (reference model/model.py:440-489) and its autograd backward
+DecoderEngine  <->  Decoder.forward          (reference model/model.py:344-365) and its autograd backward
+Every arithmetic step is a libzs_amd.so kernel; torch only owns the memory.
+"""
+import torch
+
+from . import _lib as L
+from .layers import Act, ConvLayer, GruLayer, rup
+
+LRELU = L.ZS_ACT_LRELU
+EPS_IN = 1e-5
+_UID = [0]
+
+
+def _uid():
+    _UID[0] += 1
+    return _UID[0]
+
+
+def _half_up(t):
+    return (t + 1) // 2
+
+
+class EncoderEngine(object):
+    def __init__(self, ctx, P, G, c_in, c_h1, c_h2, c_h3, enc_size, ns, dp, seg_len):
+        """P / G: dicts name -> fp32 parameter / gradient tensors (reference state_dict names)."""
+        self.ctx = ctx
+        self.uid = _uid()
+        self.c_in, self.c1, self.c2, self.H, self.E = c_in, c_h1, c_h2, c_h3, enc_size
+        self.ns, self.dp = float(ns), float(dp)
+        self.pad_mode = L.ZS_PAD_REFLECT if seg_len >= 64 else L.ZS_PAD_ZERO     # model/model.py:38
+        if c_h1 % 8 or c_h2 % 8:
+            raise ValueError('c_h1 and c_h2 must be multiples of 8 (16-byte rows)')
+        mk = lambda n, **kw: ConvLayer(ctx, P[n + '.weight'], P[n + '.bias'], G[n + '.weight'], G[n + '.bias'],
+                                       pad_mode=self.pad_mode, name=n, **kw)
+        self.conv1s = [mk('conv1s.%d' % i) for i in range(7)]
+        self.conv2 = mk('conv2')
+        self.convs = [(mk('conv%d' % a), mk('conv%d' % b, stride=2)) for a, b in ((3, 4), (5, 6), (7, 8))]
+        self.dense = [(mk('dense%d' % a), mk('dense%d' % b)) for a, b in ((1, 2), (3, 4))]
+        self.gru = GruLayer(ctx, P, G, 'RNN.', name='enc%d' % self.uid)
+        self.linear = mk('linear')
+        self.layers = self.conv1s + [self.conv2] + [l for p in self.convs for l in p] + [l for p in self.dense for l in p] + \
+            [self.linear]
+        self.ncat = 7 * c_h1 + c_in
+        self.tape = None
+
+    def pack(self):
+        for l in self.layers:
+            l.pack()
+        self.gru.pack()
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, x, training, noise=None, noise_kind=2, seed=0, drop_masks=None):
+        """x: fp32 [B, T, c_in] contiguous on device.  Returns (bits Act [B,T',E] (T dtype, feeds the decoder),
+        bits_f32 [B,T',E], logits_f32 [B,T',ld]).  noise: fp32 [B,T',E,2] (Gumbel if noise_kind 0, uniform if 1)."""
+        c, ns = self.ctx, self.ns
+        B, T, F = x.shape
+        assert F == self.c_in and x.dtype == torch.float32 and x.is_contiguous()
+        st = c.stream
+        c1, c2, H, E = self.c1, self.c2, self.H, self.E
+        dp = self.dp if training else 0.0
+        masks = drop_masks if drop_masks is not None else [None] * 6
+        Ts = [T, _half_up(T), _half_up(_half_up(T)), _half_up(_half_up(_half_up(T)))]
+        T4 = Ts[3]
+        tag = '_%d_%d_%d' % (self.uid, B, T)
+        tp = {'B': B, 'T': T, 'Ts': Ts, 'training': training, 'seed': seed, 'masks': masks, 'dp': dp}
+
+        xin = c.act('e_xin' + tag, B, T, F)
+        cat = c.act('e_cat' + tag, B, T, self.ncat)
+        L.call('zs_cast_rows', 'ZsCastRows', st, dtype=c.dt, src=L.ptr(x), ld_src=F, src_f32=1, dst=xin.ptr(), ld_dst=xin.ld,
+               dst_f32=0, col_off=0, rows=B * T, cols=F, fill_cols=xin.ld, act=L.ZS_ACT_NONE)
+        L.call('zs_cast_rows', 'ZsCastRows', st, dtype=c.dt, src=L.ptr(x), ld_src=F, src_f32=1, dst=cat.ptr(), ld_dst=cat.ld,
+               dst_f32=0, col_off=7 * c1, rows=B * T, cols=F, fill_cols=cat.ld - 7 * c1, act=LRELU, slope=ns)   # :445-446
+        for i, l in enumerate(self.conv1s):                                                                   # :441-444
+            l.fwd(xin, out=cat.sub(i * c1, c1), act=LRELU, slope=ns)
+        y2 = c.act('e_y2' + tag, B, T, c2)
+        self.conv2.fwd(cat, out=y2, act=LRELU, slope=ns)                                                      # :447
+        a = c.act('e_a0' + tag, B, T, c2)
+        st0 = self._in(y2, a, tp, 0, res_mode=L.ZS_RES_NONE)
+        tp.update(xin=xin, cat=cat, y2=y2, a0=a, st0=st0, blocks=[], dense=[])
+        for i, (la, lb) in enumerate(self.convs):                                                            # :448-450
+            ya = c.act('e_ya%d' % i + tag, B, Ts[i], c2)
+            la.fwd(a, out=ya, act=LRELU, slope=ns)
+            yb = c.act('e_yb%d' % i + tag, B, Ts[i + 1], c2)
+            lb.fwd(ya, out=yb, act=LRELU, slope=ns)
+            an = c.act('e_a%d' % (i + 1) + tag, B, Ts[i + 1], c2)
+            stt = self._in(yb, an, tp, 1 + i, res_mode=L.ZS_RES_AVGPOOL2, res=a)
+            tp['blocks'].append((a, ya, yb, stt))
+            a = an
+        cat2 = c.act('e_cat2' + tag, B, T4, c2 + 2 * H)
+        for j, (la, lb) in enumerate(self.dense):                                                            # :452-453
+            d1 = c.act('e_d1%d' % j + tag, B, T4, c2)
+            la.fwd(a, out=d1, act=LRELU, slope=ns)
+            d2 = c.act('e_d2%d' % j + tag, B, T4, c2)
+            lb.fwd(d1, out=d2, act=LRELU, slope=ns)
+            out = c.act('e_do%d' % j + tag, B, T4, c2) if j == 0 else Act(cat2.t, B, T4, c2, cat2.ld, 0, rup(c2, 32))
+            stt = self._in(d2, out, tp, 4 + j, res_mode=L.ZS_RES_IDENTITY, res=a)
+            tp['dense'].append((a, d1, d2, stt))
+            a = out
+        gi = c.act('e_gi' + tag, B, T4, 6 * H)
+        gates = c.raw('e_gates' + tag, B * T4 * 8 * H, c.tdt) if training else None
+        self.gru.fwd(a, cat2, c2, gi, gates)                                                                 # :454-455
+        logits = c.act('e_logits' + tag, B, T4, 2 * E, dtype=torch.float32)
+        self.linear.fwd(cat2, out=logits, out_f32=True)                                                      # :475
+        bits = c.act('e_bits' + tag, B, T4, E)
+        bits_f32 = c.f32('e_bitsf' + tag, B * T4 * E)
+        y0 = c.f32('e_y0' + tag, B * T4 * E)
+        L.call('zs_mbv_fwd', 'ZsMbvFwd', st, dtype=c.dt, logits=logits.ptr(), ld=logits.ld, logits_f32=1,
+               noise=L.ptr(noise), noise_kind=noise_kind, seed=seed, rows=B * T4, E=E, tau=0.1, bits=bits.ptr(),
+               ld_bits=bits.ld, bits_fill_cols=bits.ld, bits_f32=L.ptr(bits_f32), y0=L.ptr(y0))               # :476-480
+        tp.update(cat2=cat2, gates=gates, y0=y0, T4=T4, gru_in=a)
+        self.tape = tp
+        return bits, bits_f32[:B * T4 * E].view(B, T4, E), logits
+
+    def _in(self, x, out, tp, k, res_mode, res=None):
+        """InstanceNorm + Dropout + residual (model/model.py:421-427, 434-437)."""
+        c = self.ctx
+        B, T, C = x.B, x.T, x.ld
+        mean = rstd = None
+        if tp['training']:
+            mean = c.f32('e_mean%d_%d_%d_%d' % (self.uid, k, B, T), B * C)
+            rstd = c.f32('e_rstd%d_%d_%d_%d' % (self.uid, k, B, T), B * C)
+        m = tp['masks'][k]
+        L.call('zs_instnorm_fwd', 'ZsInstNormFwd', c.stream, dtype=c.dt, x=x.ptr(), ldx=x.ld, out=out.ptr(), ldo=out.ld,
+               mean=L.ptr(mean), rstd=L.ptr(rstd), B=B, T=T, C=C, eps=EPS_IN, drop_p=tp['dp'], seed=tp['seed'],
+               stream_id=k + 1, mask=L.ptr(m), mask_ld=(m.shape[-1] if m is not None else 0), res_mode=res_mode,
+               res=(res.ptr() if res is not None else None), ldres=(res.ld if res is not None else 0),
+               T_res=(res.T if res is not None else 0), res_pad_mode=self.pad_mode)
+        return (mean, rstd, k)
+
+    def _in_bwd(self, dout, x, stt, dz, tp):
+        c = self.ctx
+        mean, rstd, k = stt
+        m = tp['masks'][k]
+        L.call('zs_instnorm_bwd', 'ZsInstNormBwd', c.stream, dtype=c.dt, dout=dout.ptr(), ldd=dout.ld, x=x.ptr(), ldx=x.ld,
+               mean=L.ptr(mean), rstd=L.ptr(rstd), dz=dz.ptr(), ldz=dz.ld, B=x.B, T=x.T, C=x.ld, drop_p=tp['dp'],
+               seed=tp['seed'], stream_id=k + 1, mask=L.ptr(m), mask_ld=(m.shape[-1] if m is not None else 0), slope=self.ns)
+
+    # ------------------------------------------------------------------------------------------
+    def backward(self, dbits):
+        """dbits: Act [B,T',E] gradient w.r.t. enc_act.  Fills every encoder parameter gradient (overwrite)."""
+        c, ns, tp = self.ctx, self.ns, self.tape
+        assert tp is not None and tp['training']
+        B, T, Ts, T4 = tp['B'], tp['T'], tp['Ts'], tp['T4']
+        c1, c2, H, E = self.c1, self.c2, self.H, self.E
+        st = c.stream
+        tag = '_%d_%d_%d' % (self.uid, B, T)
+        cat2 = tp['cat2']
+        dlog = c.act('e_dlog' + tag, B, T4, 2 * E)
+        L.call('zs_mbv_bwd', 'ZsMbvBwd', st, dtype=c.dt, dbits=dbits.ptr(), ld_dbits=dbits.ld, y0=L.ptr(tp['y0']),
+               rows=B * T4, E=E, tau=0.1, dlogits=dlog.ptr(), ld=dlog.ld, fill_cols=dlog.ld)
+        self.linear.wgrad(dlog, cat2)
+        dcat2 = c.act('e_dcat2' + tag, B, T4, cat2.C)
+        self.linear.dgrad(dlog, T4, dcat2)
+        dgi = c.act('e_dgi' + tag, B, T4, 6 * H)
+        dgh = c.act('e_dgh' + tag, B, T4, 6 * H)
+        gin = tp['gru_in']
+        da = c.act('e_da_d' + tag, B, T4, c2)
+        self.gru.bwd(dcat2, c2, cat2, c2, tp['gates'], gin, dgi, dgh, da, add_src=dcat2)
+        for j in (1, 0):
+            la, lb = self.dense[j]
+            xin, d1, d2, stt = tp['dense'][j]
+            dz2 = c.act('e_dz2' + tag, B, T4, c2)
+            self._in_bwd(da, d2, stt, dz2, tp)
+            lb.wgrad(dz2, d1)
+            dz1 = c.act('e_dz1' + tag, B, T4, c2)
+            lb.dgrad(dz2, T4, dz1, dact_src=d1, slope=ns)
+            la.wgrad(dz1, xin)
+            dn = c.act('e_da_d%d' % j + tag, B, T4, c2)
+            la.dgrad(dz1, T4, dn, add_src=da)
+            da = dn
+        for i in (2, 1, 0):
+            la, lb = self.convs[i]
+            a, ya, yb, stt = tp['blocks'][i]
+            dzb = c.act('e_dzb%d' % i + tag, B, Ts[i + 1], c2)
+            self._in_bwd(da, yb, stt, dzb, tp)
+            lb.wgrad(dzb, ya)
+            gp = c.act('e_gp%d' % i + tag, B, Ts[i] + 4, c2)
+            lb.dgrad(dzb, Ts[i], gp)
+            dza = c.act('e_dza%d' % i + tag, B, Ts[i], c2)
+            self._combine(gp, Ts[i], 2, 2, dza, dact=ya)
+            la.wgrad(dza, a)
+            la.dgrad(dza, Ts[i], gp)
+            dn = c.act('e_da%d' % i + tag, B, Ts[i], c2)
+            self._combine(gp, Ts[i], 2, 2, dn, res_mode=L.ZS_RES_AVGPOOL2, res=da)
+            da = dn
+        y2, cat, xin = tp['y2'], tp['cat'], tp['xin']
+        dz = c.act('e_dzy2' + tag, B, T, c2)
+        self._in_bwd(da, y2, tp['st0'], dz, tp)
+        self.conv2.wgrad(dz, cat)
+        dcat = c.act('e_dcat' + tag, B, T, self.ncat)
+        self.conv2.dgrad(dz, T, dcat, dact_src=cat, slope=ns)
+        for i, l in enumerate(self.conv1s):
+            l.wgrad(dcat.sub(i * c1, c1), xin)
+
+    def _combine(self, gp, T, pl, pr, out, res_mode=L.ZS_RES_NONE, res=None, dact=None):
+        c = self.ctx
+        L.call('zs_grad_combine', 'ZsGradCombine', c.stream, dtype=c.dt, gp=gp.ptr(), ldg=gp.ld, pad_left=pl, pad_right=pr,
+               pad_mode=self.pad_mode, B=gp.B, T=T, C=gp.ld, res_mode=res_mode, res=(res.ptr() if res is not None else None),
+               ldres=(res.ld if res is not None else 0), dact_src=(dact.ptr() if dact is not None else None),
+               dact_ld=(dact.ld if dact is not None else 0), slope=self.ns, out=out.ptr(), ldo=out.ld, unshuffle=0)
+
+
+class DecoderEngine(object):
+    def __init__(self, ctx, P, G, c_in, c_out, c_h, c_a, ns, seg_len, output_mask=False):
+        self.ctx = ctx
+        self.uid = _uid()
+        self.E, self.F, self.ch, self.n_spk = c_in, c_out, c_h, c_a
+        self.ns = float(ns)
+        self.pad_mode = L.ZS_PAD_REFLECT if seg_len >= 64 else L.ZS_PAD_ZERO
+        self.out_act = L.ZS_ACT_TANH if output_mask else L.ZS_ACT_SIGMOID
+        if c_h % 32:
+            raise ValueError('Decoder c_h must be a multiple of 32 (got %d)' % c_h)
+        mk = lambda n, **kw: ConvLayer(ctx, P[n + '.weight'], P[n + '.bias'], G[n + '.weight'], G[n + '.bias'],
+                                       pad_mode=self.pad_mode, name=n, **kw)
+        self.input_emb = mk('input_emb')
+        self.convs = [(mk('conv%d' % a, split2=True), mk('conv%d' % b)) for a, b in ((1, 2), (3, 4), (5, 6))]
+        self.dense = [(mk('dense%d' % a), mk('dense%d' % b)) for a, b in ((1, 2), (3, 4))]
+        self.gru = GruLayer(ctx, P, G, 'RNN.', name='dec%d' % self.uid)
+        self.dense5, self.linear = mk('dense5'), mk('linear')
+        self.emb = [P['emb%d.weight' % i] for i in range(1, 6)]
+        self.gemb = [G['emb%d.weight' % i] for i in range(1, 6)]
+        self.layers = [self.input_emb] + [l for p in self.convs for l in p] + [l for p in self.dense for l in p] + \
+            [self.dense5, self.linear]
+        self.tape = None
+
+    def pack(self):
+        for l in self.layers:
+            l.pack()
+        self.gru.pack()
+
+    def forward(self, bits, cidx, training):
+        """bits: Act [B,T',E] (T dtype, zero padded); cidx int64 [B].  Returns x_dec Act fp32 [B, 8T', F]."""
+        c, ns, ch = self.ctx, self.ns, self.ch
+        B, T0 = bits.B, bits.T
+        tag = '_%d_%d_%d' % (self.uid, B, T0)
+        st = c.stream
+        emb = self.emb
+        tp = {'B': B, 'T0': T0, 'training': training, 'cidx': cidx, 'bits': bits, 'blocks': [], 'dense': []}
+        x = c.act('d_x0' + tag, B, T0, ch)
+        xe = c.act('d_xe0' + tag, B, T0, ch)
+        self.input_emb.fwd(bits, out=x, out2=xe, vec2=emb[0], idx=cidx)                                   # :346, :319
+        T = T0
+        for i, (la, lb) in enumerate(self.convs):                                                        # :317-331
+            ya = c.act('d_ya%d' % i + tag, B, T, 2 * ch) if training else None
+            s = c.act('d_s%d' % i + tag, B, 2 * T, ch)
+            la.fwd(xe, out=ya, act=LRELU, slope=ns, out2=s, vec2=emb[i], idx=cidx, store_mode2=L.ZS_STORE_SPLIT2)
+            yb = c.act('d_yb%d' % i + tag, B, 2 * T, ch)
+            lb.fwd(s, out=yb, act=LRELU, slope=ns)
+            xn = c.act('d_x%d' % (i + 1) + tag, B, 2 * T, ch)
+            xen = c.act('d_xe%d' % (i + 1) + tag, B, 2 * T, ch)
+            nxt = emb[i + 1] if i < 2 else emb[3]                                                        # emb2, emb3, then emb4 (:350)
+            stt = self._in(yb, xn, xen, nxt, cidx, L.ZS_RES_UPSAMPLE2, x, training, 'c%d' % i)
+            tp['blocks'].append((x, xe, ya, s, yb, stt, T))
+            x, xe, T = xn, xen, 2 * T
+        cat3 = c.act('d_cat3' + tag, B, T, 3 * ch)
+        for j, (la, lb) in enumerate(self.dense):                                                        # :333-342, :350-351
+            y1 = c.act('d_y1%d' % j + tag, B, T, ch)
+            y1e = c.act('d_y1e%d' % j + tag, B, T, ch)
+            la.fwd(xe, out=y1, act=LRELU, slope=ns, out2=y1e, vec2=emb[3], idx=cidx)
+            y2 = c.act('d_y2%d' % j + tag, B, T, ch)
+            lb.fwd(y1e, out=y2, act=LRELU, slope=ns)
+            xn = c.act('d_dx%d' % j + tag, B, T, ch) if j == 0 else Act(cat3.t, B, T, ch, cat3.ld, 0, ch)
+            xen = c.act('d_dxe%d' % j + tag, B, T, ch)
+            stt = self._in(y2, xn, xen, emb[3] if j == 0 else emb[4], cidx, L.ZS_RES_IDENTITY, x, training, 'd%d' % j)
+            tp['dense'].append((x, xe, y1, y1e, y2, stt))
+            x, xe = xn, xen
+        H = ch // 2
+        gi = c.act('d_gi' + tag, B, T, 6 * H)
+        gates = c.raw('d_gates' + tag, B * T * 8 * H, c.tdt) if training else None
+        self.gru.fwd(xe, cat3, ch, gi, gates)                                                            # :352-356
+        L.call('zs_add_rowvec', 'ZsAddRowvec', st, dtype=c.dt, x=None, vec=L.ptr(emb[4]), vec_ld=ch, idx=L.ptr(cidx),
+               out=cat3.ptr(2 * ch), ldo=cat3.ld, B=B, T=T, C=ch, fill_cols=ch)                           # :357 append_emb
+        h5 = c.act('d_h5' + tag, B, T, ch)
+        self.dense5.fwd(cat3, out=h5, act=LRELU, slope=ns)                                               # :358-359
+        xdec = c.act('d_xdec' + tag, B, T, self.F, dtype=torch.float32)
+        self.linear.fwd(h5, out=xdec, act=self.out_act, out_f32=True)                                    # :360-364
+        tp.update(cat3=cat3, gates=gates, gru_in=xe, h5=h5, T=T)
+        self.tape = tp
+        return xdec
+
+    def _in(self, x, out, out2, vec2, cidx, res_mode, res, training, key):
+        c = self.ctx
+        B, T, C = x.B, x.T, x.ld
+        mean = rstd = None
+        if training:
+            mean = c.f32('d_mean%d_%s_%d_%d' % (self.uid, key, B, T), B * C)
+            rstd = c.f32('d_rstd%d_%s_%d_%d' % (self.uid, key, B, T), B * C)
+        L.call('zs_instnorm_fwd', 'ZsInstNormFwd', c.stream, dtype=c.dt, x=x.ptr(), ldx=x.ld, out=out.ptr(), ldo=out.ld,
+               out2=out2.ptr(), ldo2=out2.ld, vec2=L.ptr(vec2), vec2_ld=vec2.shape[1], vec2_cols=vec2.shape[1], idx=L.ptr(cidx),
+               mean=L.ptr(mean), rstd=L.ptr(rstd), B=B, T=T, C=C, eps=EPS_IN, drop_p=0.0, res_mode=res_mode, res=res.ptr(),
+               ldres=res.ld, T_res=res.T, res_pad_mode=self.pad_mode)
+        return (mean, rstd)
+
+    def _in_bwd(self, dout, x, stt, dz):
+        c = self.ctx
+        L.call('zs_instnorm_bwd', 'ZsInstNormBwd', c.stream, dtype=c.dt, dout=dout.ptr(), ldd=dout.ld, x=x.ptr(), ldx=x.ld,
+               mean=L.ptr(stt[0]), rstd=L.ptr(stt[1]), dz=dz.ptr(), ldz=dz.ld, B=x.B, T=x.T, C=x.ld, drop_p=0.0, slope=self.ns)
+
+    def _combine(self, gp, T, pl, pr, out, emb_i=None, res_mode=L.ZS_RES_NONE, res=None, dact=None, unshuffle=0, C=None):
+        c = self.ctx
+        esum = None
+        if emb_i is not None:                      # per-sample sums for embedding emb_i (finished by zs_emb_scatter)
+            esum = L.ptr(self._embsum, emb_i * gp.B * self.ch)
+        L.call('zs_grad_combine', 'ZsGradCombine', c.stream, dtype=c.dt, gp=gp.ptr(), ldg=gp.ld, pad_left=pl, pad_right=pr,
+               pad_mode=self.pad_mode, B=gp.B, T=T, C=(C if C is not None else self.ch),
+               emb_sum=esum, emb_ld=self.ch, emb_cols=self.ch, res_mode=res_mode,
+               res=(res.ptr() if res is not None else None), ldres=(res.ld if res is not None else 0),
+               dact_src=(dact.ptr() if dact is not None else None), dact_ld=(dact.ld if dact is not None else 0),
+               slope=self.ns, out=(out.ptr() if out is not None else None), ldo=(out.ld if out is not None else 0),
+               unshuffle=unshuffle)
+
+    def backward(self, dlogit, need_dbits=True):
+        """dlogit: Act [B,T,F] gradient w.r.t. the pre-sigmoid output.  Fills (overwrites) every decoder parameter
+        gradient.  Returns dbits Act [B,T',E]."""
+        c, ns, ch, tp = self.ctx, self.ns, self.ch, self.tape
+        assert tp is not None and tp['training']
+        B, T0, T = tp['B'], tp['T0'], tp['T']
+        tag = '_%d_%d_%d' % (self.uid, B, T0)
+        cat3, h5 = tp['cat3'], tp['h5']
+        H = ch // 2
+        self._embsum = c.f32('d_embsum' + tag, 5 * B * ch)
+        self._embsum.zero_()
+        self.linear.wgrad(dlogit, h5)
+        dz5 = c.act('d_dz5' + tag, B, T, ch)
+        self.linear.dgrad(dlogit, T, dz5, dact_src=h5, slope=ns)
+        self.dense5.wgrad(dz5, cat3)
+        dcat3 = c.act('d_dcat3' + tag, B, T, 3 * ch)
+        self.dense5.dgrad(dz5, T, dcat3)
+        self._combine(dcat3.sub(2 * ch, ch), T, 0, 0, None, emb_i=4)                       # d emb5 via append_emb
+        dgi = c.act('d_dgi' + tag, B, T, 6 * H)
+        dgh = c.act('d_dgh' + tag, B, T, 6 * H)
+        gp = c.act('d_gpA' + tag, B, T + 2, ch)
+        gpv = Act(gp.t, B, T, ch, gp.ld)
+        self.gru.bwd(dcat3, ch, cat3, ch, tp['gates'], tp['gru_in'], dgi, dgh, gpv)
+        dx = c.act('d_dxA' + tag, B, T, ch)
+        self._combine(gpv, T, 0, 0, dx, emb_i=4, res_mode=L.ZS_RES_IDENTITY, res=dcat3.sub(0, ch))   # out+emb5 (:353)
+        for j in (1, 0):
+            la, lb = self.dense[j]
+            xin, xe, y1, y1e, y2, stt = tp['dense'][j]
+            dz2 = c.act('d_dz2' + tag, B, T, ch)
+            self._in_bwd(dx, y2, stt, dz2)
+            lb.wgrad(dz2, y1e)
+            lb.dgrad(dz2, T, gpv)
+            dz1 = c.act('d_dz1' + tag, B, T, ch)
+            self._combine(gpv, T, 0, 0, dz1, emb_i=3, dact=y1)
+            la.wgrad(dz1, xe)
+            la.dgrad(dz1, T, gpv)
+            dn = c.act('d_dxD%d' % j + tag, B, T, ch)
+            self._combine(gpv, T, 0, 0, dn, emb_i=3, res_mode=L.ZS_RES_IDENTITY, res=dx)
+            dx = dn
+        for i in (2, 1, 0):
+            la, lb = self.convs[i]
+            xin, xe, ya, s, yb, stt, Ti = tp['blocks'][i]
+            T2 = 2 * Ti
+            dzb = c.act('d_dzb%d' % i + tag, B, T2, ch)
+            self._in_bwd(dx, yb, stt, dzb)
+            lb.wgrad(dzb, s)
+            gp2 = Act(gp.t, B, T2 + 2, ch, gp.ld)
+            lb.dgrad(dzb, T2, gp2)
+            dza = c.act('d_dza%d' % i + tag, B, Ti, 2 * ch)
+            self._combine(gp2, T2, 1, 1, dza, emb_i=i, dact=ya, unshuffle=1)                # pixel_shuffle^T, +emb (:323-324)
+            la.wgrad(dza, xe)
+            gp1 = Act(gp.t, B, Ti + 2, ch, gp.ld)
+            la.dgrad(dza, Ti, gp1)
+            dn = c.act('d_dxC%d' % i + tag, B, Ti, ch)
+            self._combine(gp1, Ti, 1, 1, dn, emb_i=i, res_mode=L.ZS_RES_UPSAMPLE2, res=dx)   # x+emb (:319) and upsample(x) (:329)
+            dx = dn
+        for k in range(5):                             # nn.Embedding backward, fixed sample order
+            L.call('zs_emb_scatter', 'ZsEmbScatter', c.stream, emb_sum=L.ptr(self._embsum, k * B * ch), emb_ld=ch,
+                   idx=L.ptr(tp['cidx']), B=B, demb=L.ptr(self.gemb[k]), demb_ld=ch, n_rows=self.n_spk, C=ch, accumulate=0)
+        bits = tp['bits']
+        self.input_emb.wgrad(dx, bits)
+        dbits = None
+        if need_dbits:
+            dbits = c.act('d_dbits' + tag, B, T0, self.E)
+            self.input_emb.dgrad(dx, T0, dbits)
+        return dbits

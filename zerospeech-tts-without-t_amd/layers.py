@@ -1,0 +1,299 @@
+"""Host-side description of the GEMM-shaped layers: operand packing and the forward / data-gradient /
+weight-gradient calls into libzs_amd.so.  PyTorch is used for device memory only."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+
+def rup(x, m):
+    return (x + m - 1) // m * m
+
+
+DTYPES = {'fp32': (L.ZS_F32, torch.float32), 'bf16': (L.ZS_BF16, torch.bfloat16)}
+SLACK = 512   # elements of zeroed slack behind every activation buffer (K-padding reads may run past a row)
+
+
+class Act(object):
+    """A channels-last activation: B*T rows of `ld` elements inside tensor `t` (1-D storage with slack),
+    starting at element offset `off`.  C valid channels; columns [C, cols) are zeros."""
+    __slots__ = ('t', 'B', 'T', 'C', 'ld', 'off', 'cols')
+
+    def __init__(self, t, B, T, C, ld, off=0, cols=None):
+        self.t, self.B, self.T, self.C, self.ld, self.off = t, B, T, C, ld, off
+        self.cols = cols if cols is not None else ld
+
+    @property
+    def rows(self):
+        return self.B * self.T
+
+    def ptr(self, col=0):
+        return self.t.data_ptr() + (self.off + col) * self.t.element_size()
+
+    def sub(self, col, C, cols=None):
+        return Act(self.t, self.B, self.T, C, self.ld, self.off + col, cols if cols is not None else C)
+
+    def view2d(self):
+        return self.t[self.off:self.off + self.rows * self.ld].view(self.rows, self.ld) if self.off == 0 else \
+            self.t[self.off - (self.off % self.ld):][:self.rows * self.ld].view(self.rows, self.ld)
+
+    def valid(self):
+        """[B, T, C] torch view of the valid part (for API outputs / tests)."""
+        base = self.t[self.off:self.off + (self.rows - 1) * self.ld + self.C]
+        return torch.as_strided(base, (self.B, self.T, self.C), (self.T * self.ld, self.ld, 1))
+
+
+class Ctx(object):
+    """Per-model execution context: device, compute dtype, cached buffers, split-K workspace."""
+
+    def __init__(self, device, dtype='fp32'):
+        if dtype not in DTYPES:
+            raise ValueError('dtype must be fp32 or bf16')
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise L.ZsError('zs_amd runs on an MI355X only (device %s requested); there is no CPU path' % device)
+        L.lib()
+        self.dtype_name = dtype
+        self.dt, self.tdt = DTYPES[dtype]
+        self.es = 4 if dtype == 'fp32' else 2
+        self._bufs = {}
+        self._ws = None
+
+    @property
+    def stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def raw(self, name, n, dtype, zero=True):
+        key = (name, n, dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            t = torch.zeros(n + SLACK, dtype=dtype, device=self.device)
+            self._bufs[key] = t
+        return t
+
+    def act(self, name, B, T, C, ld=None, dtype=None):
+        ld = ld if ld is not None else rup(C, 32)
+        dtype = dtype if dtype is not None else self.tdt
+        return Act(self.raw(name, B * T * ld, dtype), B, T, C, ld)
+
+    def f32(self, name, n):
+        return self.raw(name, n, torch.float32)
+
+    def workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def release(self):
+        self._bufs.clear()
+        self._ws = None
+
+
+class ConvLayer(object):
+    """Conv1d [Cout,Cin,k] or Linear [Cout,Cin] (k=1) as packed MFMA operands.
+    split2: output channels packed so that the epilogue can pixel-shuffle (see zs_amd.h)."""
+
+    def __init__(self, ctx, weight, bias, gweight, gbias, stride=1, split2=False, pad_mode=L.ZS_PAD_REFLECT, name=''):
+        self.ctx, self.name = ctx, name
+        self.w, self.b, self.gw, self.gb = weight, bias, gweight, gbias
+        self.Cout, self.Cin = weight.shape[0], weight.shape[1]
+        self.k = weight.shape[2] if weight.dim() == 3 else 1
+        self.stride, self.split2, self.pad_mode = stride, split2, pad_mode
+        self.pad_l = self.k // 2
+        self.pad_r = self.k - 1 - self.k // 2
+        self.so, self.si, self.sj = (self.Cin * self.k, self.k, 1) if weight.dim() == 3 else (self.Cin, 1, 0)
+        self.cin_pad, self.cout_pad = rup(self.Cin, 32), rup(self.Cout, 32)
+        self.ldw, self.n_pad = rup(self.k * self.cin_pad, 64), rup(self.Cout, 128)
+        self.ldw_d, self.n_pad_d = rup(self.k * self.cout_pad, 64), rup(self.Cin, 128)
+        dev, tdt = ctx.device, ctx.tdt
+        self.wf = torch.zeros(self.n_pad * self.ldw + SLACK, dtype=tdt, device=dev)
+        self.wd = torch.zeros(self.n_pad_d * self.ldw_d + SLACK, dtype=tdt, device=dev)
+        self.bias_p = torch.zeros(self.Cout, dtype=torch.float32, device=dev) if (split2 and bias is not None) else None
+
+    def pack(self):
+        c = self.ctx
+        common = dict(dtype=c.dt, W=L.ptr(self.w), so=self.so, si=self.si, sj=self.sj, Cout=self.Cout, Cin=self.Cin,
+                      taps=self.k, co_split2=int(self.split2))
+        L.call('zs_pack_weight', 'ZsPackWeight', c.stream, transpose=0, inner_pad=self.cin_pad, dst=L.ptr(self.wf),
+               ldw=self.ldw, n_rows=self.n_pad, n_cols=self.ldw, **common)
+        L.call('zs_pack_weight', 'ZsPackWeight', c.stream, transpose=1, inner_pad=self.cout_pad, dst=L.ptr(self.wd),
+               ldw=self.ldw_d, n_rows=self.n_pad_d, n_cols=self.ldw_d, **common)
+        if self.bias_p is not None:
+            h = self.Cout // 2
+            self.bias_p[:h].copy_(self.b[0::2])
+            self.bias_p[h:].copy_(self.b[1::2])
+
+    def bias_ptr(self):
+        if self.b is None:
+            return None
+        return L.ptr(self.bias_p if self.bias_p is not None else self.b)
+
+    def t_out(self, T_in):
+        return (T_in + self.pad_l + self.pad_r - self.k) // self.stride + 1
+
+    def fwd(self, A, out=None, act=L.ZS_ACT_NONE, slope=0.0, out_f32=False, out_cols=None, store_mode=L.ZS_STORE_ROWS,
+            out2=None, vec2=None, idx=None, store_mode2=L.ZS_STORE_ROWS, out2_cols=None, pre_vec=None):
+        """A: Act [B,T_in,Cin] -> out Act [B,T_out,Cout] (or pixel-shuffled).  Returns T_out."""
+        c = self.ctx
+        T_out = self.t_out(A.T)
+        assert A.ld >= self.cin_pad or A.cols >= self.cin_pad, (self.name, A.ld, self.cin_pad)
+        kw = dict(dtype=c.dt, A=A.ptr(), lda=A.ld, a_batch_stride=A.T * A.ld, B=A.B, T_in=A.T, T_out=T_out, taps=self.k,
+                  stride=self.stride, pad_left=self.pad_l, pad_mode=self.pad_mode, gather=0, cin_pad=self.cin_pad,
+                  W=L.ptr(self.wf), ldw=self.ldw, N=self.Cout, n_pad=self.n_pad, bias=self.bias_ptr(), act=act, slope=slope,
+                  groups=1)
+        if pre_vec is not None:
+            kw.update(pre_vec=L.ptr(pre_vec), pre_vec_ld=pre_vec.shape[1], vec_idx=L.ptr(idx))
+        if out is not None:
+            kw.update(out=out.ptr(), ldc=out.ld, out_f32=int(out_f32), store_mode=store_mode,
+                      out_cols=out_cols if out_cols is not None else (min(out.cols, rup(self.Cout, 32)) if store_mode == L.ZS_STORE_ROWS else self.Cout // 2))
+        if out2 is not None:
+            kw.update(out2=out2.ptr(), ldc2=out2.ld, store_mode2=store_mode2,
+                      out2_cols=out2_cols if out2_cols is not None else (min(out2.cols, rup(self.Cout, 32)) if store_mode2 == L.ZS_STORE_ROWS else self.Cout // 2))
+            if vec2 is not None:
+                kw.update(vec2=L.ptr(vec2), vec2_ld=vec2.shape[1], vec_idx=L.ptr(idx))
+        L.call('zs_gemm_conv', 'ZsGemmConv', c.stream, **kw)
+        return T_out
+
+    def dgrad(self, dY, T_x, out, dact_src=None, slope=0.0, add_src=None):
+        """dY: Act [B,T_y,Cout] (ld >= cout_pad).  out: Act with B*(T_x+pad_l+pad_r) rows (padded domain; equals the
+        input gradient when k == 1).  Optional epilogue: *lrelu'(dact_src), +add_src (both only meaningful for k == 1)."""
+        c = self.ctx
+        Tp = T_x + self.pad_l + self.pad_r
+        kw = dict(dtype=c.dt, A=dY.ptr(), lda=dY.ld, a_batch_stride=dY.T * dY.ld, B=dY.B, T_in=dY.T, T_out=Tp, taps=self.k,
+                  stride=self.stride, pad_left=0, pad_mode=L.ZS_PAD_ZERO, gather=1, cin_pad=self.cout_pad,
+                  W=L.ptr(self.wd), ldw=self.ldw_d, N=self.Cin, n_pad=self.n_pad_d, act=L.ZS_ACT_NONE, slope=slope,
+                  out=out.ptr(), ldc=out.ld, out_cols=min(out.cols, self.cin_pad), store_mode=L.ZS_STORE_ROWS, groups=1)
+        if dact_src is not None:
+            kw.update(dact_src=dact_src.ptr(), dact_ld=dact_src.ld)
+        if add_src is not None:
+            kw.update(add_src=add_src.ptr(), add_ld=add_src.ld, add_f32=0)
+        L.call('zs_gemm_conv', 'ZsGemmConv', c.stream, **kw)
+        return Tp
+
+    def wgrad(self, dY, X, accumulate=False):
+        """gw (+)= dY^T * gather(X);  gb (+)= column sums of dY (same kernel, no atomics)."""
+        c = self.ctx
+        es = c.es
+        y_cols = min(dY.cols, rup(self.Cout, 16 // es))
+        x_cols = min(X.cols, rup(self.Cin, 16 // es))
+        kw = dict(dtype=c.dt, dY=dY.ptr(), ldy=dY.ld, y_cols=y_cols, X=X.ptr(), ldx=X.ld, x_batch_stride=X.T * X.ld,
+                  x_cols=x_cols, B=X.B, T_in=X.T, T_out=dY.T, taps=self.k, stride=self.stride, pad_left=self.pad_l,
+                  pad_mode=self.pad_mode, Cout=self.Cout, Cin=self.Cin, dW=L.ptr(self.gw), so=self.so, si=self.si, sj=self.sj,
+                  db=L.ptr(self.gb), co_split2=int(self.split2), accumulate=int(accumulate), splits=0)
+        wgrad_call(c, kw)
+
+
+def wgrad_call(ctx, kw):
+    S = L.STRUCTS['ZsGemmWgrad']
+    s = S()
+    for k, v in kw.items():
+        if v is not None:
+            setattr(s, k, v)
+    need = L.lib().zs_gemm_wgrad_workspace_bytes(ctypes.byref(s))
+    ws = ctx.workspace(need)
+    s.workspace = ws.data_ptr()
+    s.workspace_bytes = ws.numel()
+    L.check(L.lib().zs_gemm_wgrad(ctypes.byref(s), ctypes.c_void_p(ctx.stream)), 'zs_gemm_wgrad')
+
+
+class GruLayer(object):
+    """Bidirectional nn.GRU (single layer).  Parameters are the 8 nn.GRU tensors (and their grads)."""
+
+    def __init__(self, ctx, P, G, prefix, name=''):
+        self.ctx, self.name = ctx, name
+        sfx = ['', '_reverse']
+        self.w_ih = [P[prefix + 'weight_ih_l0' + s] for s in sfx]
+        self.w_hh = [P[prefix + 'weight_hh_l0' + s] for s in sfx]
+        self.b_ih = [P[prefix + 'bias_ih_l0' + s] for s in sfx]
+        self.b_hh = [P[prefix + 'bias_hh_l0' + s] for s in sfx]
+        self.gw_ih = [G[prefix + 'weight_ih_l0' + s] for s in sfx]
+        self.gw_hh = [G[prefix + 'weight_hh_l0' + s] for s in sfx]
+        self.gb_ih = [G[prefix + 'bias_ih_l0' + s] for s in sfx]
+        self.gb_hh = [G[prefix + 'bias_hh_l0' + s] for s in sfx]
+        self.H = self.w_hh[0].shape[1]
+        self.Cin = self.w_ih[0].shape[1]
+        H, Cin = self.H, self.Cin
+        if H % 8:
+            raise ValueError('GRU hidden size must be a multiple of 8 (got %d)' % H)
+        dev, tdt = ctx.device, ctx.tdt
+        self.G6 = 6 * H
+        self.g6_pad = rup(6 * H, 32)
+        # input projection, both directions stacked on the output axis: [6H][Cin]
+        self.cin_pad = rup(Cin, 32)
+        self.ih_ldw, self.ih_npad = rup(self.cin_pad, 64), rup(6 * H, 128)
+        self.wih_f = torch.zeros(self.ih_npad * self.ih_ldw + SLACK, dtype=tdt, device=dev)
+        self.ih_ldw_d, self.ih_npad_d = rup(self.g6_pad, 64), rup(Cin, 128)
+        self.wih_d = torch.zeros(self.ih_npad_d * self.ih_ldw_d + SLACK, dtype=tdt, device=dev)
+        self.bih = torch.zeros(6 * H, dtype=torch.float32, device=dev)
+        # recurrent: forward [2][n_pad(3H)][ldw(H)], transposed [2][n_pad(H)][ldw(3H)]
+        self.hh_ldw, self.hh_npad = rup(rup(H, 32), 64), rup(3 * H, 128)
+        self.whh_f = torch.zeros(2 * self.hh_npad * self.hh_ldw + SLACK, dtype=tdt, device=dev)
+        self.hh_ldw_t, self.hh_npad_t = rup(rup(3 * H, 32), 64), rup(H, 128)
+        self.whh_t = torch.zeros(2 * self.hh_npad_t * self.hh_ldw_t + SLACK, dtype=tdt, device=dev)
+        self.bhh = torch.zeros(2 * 3 * H, dtype=torch.float32, device=dev)
+
+    def pack(self):
+        c, H, Cin = self.ctx, self.H, self.Cin
+        for d in range(2):
+            com = dict(dtype=c.dt, so=Cin, si=1, sj=0, Cout=3 * H, Cin=Cin, taps=1, co_split2=0, W=L.ptr(self.w_ih[d]))
+            L.call('zs_pack_weight', 'ZsPackWeight', c.stream, transpose=0, inner_pad=self.cin_pad, dst=L.ptr(self.wih_f),
+                   ldw=self.ih_ldw, n_rows=3 * H, n_cols=self.ih_ldw, row_offset=3 * H * d, **com)
+            L.call('zs_pack_weight', 'ZsPackWeight', c.stream, transpose=1, inner_pad=3 * H, dst=L.ptr(self.wih_d),
+                   ldw=self.ih_ldw_d, n_rows=self.ih_npad_d, n_cols=3 * H, col_offset=3 * H * d, **com)
+            com = dict(dtype=c.dt, so=H, si=1, sj=0, Cout=3 * H, Cin=H, taps=1, co_split2=0, W=L.ptr(self.w_hh[d]))
+            L.call('zs_pack_weight', 'ZsPackWeight', c.stream, transpose=0, inner_pad=rup(H, 32),
+                   dst=L.ptr(self.whh_f, d * self.hh_npad * self.hh_ldw), ldw=self.hh_ldw, n_rows=self.hh_npad,
+                   n_cols=self.hh_ldw, **com)
+            L.call('zs_pack_weight', 'ZsPackWeight', c.stream, transpose=1, inner_pad=rup(3 * H, 32),
+                   dst=L.ptr(self.whh_t, d * self.hh_npad_t * self.hh_ldw_t), ldw=self.hh_ldw_t, n_rows=self.hh_npad_t,
+                   n_cols=self.hh_ldw_t, **com)
+            self.bih[3 * H * d:3 * H * (d + 1)].copy_(self.b_ih[d])
+            self.bhh[3 * H * d:3 * H * (d + 1)].copy_(self.b_hh[d])
+
+    def _work(self, B):
+        n = L.lib().zs_gru_work_bytes(B, self.H)
+        return self.ctx.f32('gru_work_%s' % self.name, (n + 3) // 4)
+
+    def fwd(self, X, out, out_col, gi, gates):
+        """X: Act [B,T,Cin]; out: Act whose columns [out_col, out_col+2H) receive h (fwd ++ bwd);
+        gi: Act [B,T,6H] scratch; gates: raw tensor (T dtype, B*T*2*4H) or None."""
+        c, H = self.ctx, self.H
+        L.call('zs_gemm_conv', 'ZsGemmConv', c.stream, dtype=c.dt, A=X.ptr(), lda=X.ld, a_batch_stride=X.T * X.ld, B=X.B,
+               T_in=X.T, T_out=X.T, taps=1, stride=1, pad_left=0, pad_mode=L.ZS_PAD_ZERO, gather=0, cin_pad=self.cin_pad,
+               W=L.ptr(self.wih_f), ldw=self.ih_ldw, N=6 * H, n_pad=self.ih_npad, bias=L.ptr(self.bih), act=L.ZS_ACT_NONE,
+               out=gi.ptr(), ldc=gi.ld, out_cols=min(gi.cols, self.g6_pad), groups=1)
+        work = self._work(X.B)
+        L.call('zs_gru_fwd', 'ZsGruFwd', c.stream, dtype=c.dt, B=X.B, T=X.T, H=H, gi=gi.ptr(), ldgi=gi.ld,
+               whh=L.ptr(self.whh_f), ldw=self.hh_ldw, n_pad=self.hh_npad, w_gstride=self.hh_npad * self.hh_ldw,
+               bhh=L.ptr(self.bhh), bhh_gstride=3 * H, out=out.ptr(), ldo=out.ld, out_col=out_col,
+               gates=L.ptr(gates) if gates is not None else None, work=L.ptr(work), work_bytes=work.numel() * 4)
+
+    def bwd(self, dout, dout_col, out, out_col, gates, X, dgi, dgh, dX, add_src=None):
+        """BPTT + parameter gradients + input gradient dX (= dgi W_ih, + add_src)."""
+        c, H = self.ctx, self.H
+        B, T = X.B, X.T
+        work = self._work(B)
+        L.call('zs_gru_bwd', 'ZsGruBwd', c.stream, dtype=c.dt, B=B, T=T, H=H, dout=dout.ptr(), ldd=dout.ld, dout_col=dout_col,
+               out=out.ptr(), ldo=out.ld, out_col=out_col, gates=L.ptr(gates), whh_t=L.ptr(self.whh_t), ldw=self.hh_ldw_t,
+               n_pad=self.hh_npad_t, w_gstride=self.hh_npad_t * self.hh_ldw_t, dgi=dgi.ptr(), ldgi=dgi.ld, dgh=dgh.ptr(),
+               ldgh=dgh.ld, work=L.ptr(work), work_bytes=work.numel() * 4)
+        for d in range(2):
+            # dW_hh[d] = sum_t dgh_t^T h_{t-1}  (dir 0: h_{t-1} = out[t-1]; dir 1: out[t+1]) ; zero rows outside
+            wgrad_call(c, dict(dtype=c.dt, dY=dgh.ptr(3 * H * d), ldy=dgh.ld, y_cols=3 * H, X=out.ptr(out_col + d * H),
+                               ldx=out.ld, x_batch_stride=T * out.ld, x_cols=H, B=B, T_in=T, T_out=T, taps=1, stride=1,
+                               pad_left=(1 if d == 0 else -1), pad_mode=L.ZS_PAD_ZERO, Cout=3 * H, Cin=H,
+                               dW=L.ptr(self.gw_hh[d]), so=H, si=1, sj=0, db=L.ptr(self.gb_hh[d]), co_split2=0,
+                               accumulate=0, splits=0))
+            wgrad_call(c, dict(dtype=c.dt, dY=dgi.ptr(3 * H * d), ldy=dgi.ld, y_cols=3 * H, X=X.ptr(), ldx=X.ld,
+                               x_batch_stride=T * X.ld, x_cols=min(X.cols, rup(self.Cin, 16 // c.es)), B=B, T_in=T, T_out=T,
+                               taps=1, stride=1, pad_left=0, pad_mode=L.ZS_PAD_ZERO, Cout=3 * H, Cin=self.Cin,
+                               dW=L.ptr(self.gw_ih[d]), so=self.Cin, si=1, sj=0, db=L.ptr(self.gb_ih[d]), co_split2=0,
+                               accumulate=0, splits=0))
+        kw = dict(dtype=c.dt, A=dgi.ptr(), lda=dgi.ld, a_batch_stride=T * dgi.ld, B=B, T_in=T, T_out=T, taps=1, stride=1,
+                  pad_left=0, pad_mode=L.ZS_PAD_ZERO, gather=0, cin_pad=self.g6_pad, W=L.ptr(self.wih_d), ldw=self.ih_ldw_d,
+                  N=self.Cin, n_pad=self.ih_npad_d, act=L.ZS_ACT_NONE, out=dX.ptr(), ldc=dX.ld,
+                  out_cols=min(dX.cols, self.cin_pad), groups=1)
+        if add_src is not None:
+            kw.update(add_src=add_src.ptr(), add_ld=add_src.ld, add_f32=0)
+        L.call('zs_gemm_conv', 'ZsGemmConv', c.stream, **kw)

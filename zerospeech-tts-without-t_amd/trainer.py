@@ -1,0 +1,252 @@
+"""Trainer surface of the reference (trainer.py:34-347) for the stage-1 autoencoder path.
+
+`Trainer(hps, data_loader, g_mode, enc_mode, log_dir)` builds Encoder / Decoder / Generator with the
+reference's constructor wiring (trainer.py:48-98), `train(model_path, flag, mode='pretrain_AE')` runs the
+`--train_ae` loop (trainer.py:320-347), `save_model` / `load_model` use the reference's checkpoint dict,
+`test_step` / `encoder_test_step` are the inference entry points convert.py calls.
+
+One training step (`ae_step`) is: Encoder fwd -> Decoder fwd -> L1 -> Decoder bwd -> [async RCCL
+all-reduce of decoder grads] -> Encoder bwd -> [all-reduce encoder grads] -> per-net grad norm -> fused
+clip + Adam(lr, betas=(0.5, 0.9)) on the flat parameter buffers.  Everything is enqueued on one HIP
+stream without host synchronisation; the loss is read back only when it is logged.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import parallel
+from .layers import Act
+from .model import Decoder, Encoder
+from .utils import Logger
+
+
+class AEStep(object):
+    """The fused --train_ae iteration (trainer.py:322-332) for one Encoder/Decoder pair:
+    fwd, L1, bwd, gradient all-reduce, per-net clip (utils.py:53-55) and Adam(betas=(0.5,0.9)) over both nets
+    (trainer.py:65-66).  All state lives on the device; nothing here synchronises with the host."""
+
+    def __init__(self, encoder, decoder, lr=1e-4, betas=(0.5, 0.9), max_grad_norm=5.0):
+        self.Encoder, self.Decoder = encoder, decoder
+        self.lr, self.betas, self.max_grad_norm = float(lr), betas, float(max_grad_norm)
+        self.adam_step = 0
+        self._opt = {}
+        dev = encoder.flat_params()[0].device
+        self.device = dev
+        for name, net in (('enc', encoder), ('dec', decoder)):
+            flat, gflat = net.flat_params()
+            self._opt[name] = dict(m=torch.zeros_like(flat), v=torch.zeros_like(flat),
+                                   sq=torch.zeros(1, dtype=torch.float32, device=dev),
+                                   part=torch.zeros(1024, dtype=torch.float64, device=dev))
+        self._loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._lpart = torch.zeros(1024, dtype=torch.float32, device=dev)
+        self.reducer = parallel.GradReducer()
+        self.xdec = None
+
+    def step(self, x_btf, c, noise=None, noise_kind=2, drop_masks=None, seed=None, update=True):
+        """x_btf: fp32 [B, T, F] on the device (the loader's native layout), c: int64 [B].
+        Returns the device scalar holding loss_rec."""
+        enc, dec = self.Encoder, self.Decoder
+        enc.train(); dec.train()
+        ee, de = enc._engine(), dec._engine()
+        ctx = ee.ctx
+        st = ctx.stream
+        B, T, F = x_btf.shape
+        if seed is None:
+            seed = (self.adam_step + 1) * 0x9E3779B97F4A7C15 % (1 << 63) + parallel.rank()
+        bits, _, _ = ee.forward(x_btf, True, noise=noise, noise_kind=noise_kind, seed=seed, drop_masks=drop_masks)
+        xdec = de.forward(bits, c, True)
+        dlogit = de.ctx.act('t_dlogit_%d_%d' % (B, T), B, xdec.T, F)
+        L.call('zs_l1_loss', 'ZsL1Loss', st, dtype=ctx.dt, x_dec=xdec.ptr(), ld_dec=xdec.ld, x=L.ptr(x_btf), ldx=F,
+               rows=B * xdec.T, F=F, dlogits=dlogit.ptr(), ldg=dlogit.ld, fill_cols=dlogit.ld, partial=L.ptr(self._lpart),
+               loss_out=L.ptr(self._loss), grad_scale=1.0)                                   # trainer.py:328
+        dbits = de.backward(dlogit)                                                          # loss.backward(), trainer.py:330
+        self.reducer.start(dec.flat_params()[1])
+        ee.backward(dbits)
+        self.reducer.start(enc.flat_params()[1])
+        self.reducer.finish()
+        self.xdec = xdec
+        if update:
+            self.optimizer_step()
+        return self._loss
+
+    def grad_norms(self):
+        """Squared per-net gradient norms as device scalars (Encoder, Decoder are clipped separately)."""
+        out = []
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        for name, net in (('enc', self.Encoder), ('dec', self.Decoder)):
+            o = self._opt[name]
+            _, gflat = net.flat_params()
+            L.check(L.lib().zs_sqnorm(L.ptr(gflat), gflat.numel(), L.ptr(o['part']), L.ptr(o['sq']), st), 'zs_sqnorm')
+            out.append(o['sq'])
+        return out
+
+    def optimizer_step(self):
+        """grad_clip([Encoder, Decoder], max_grad_norm) + ae_opt.step()  (trainer.py:331-332)."""
+        self.grad_norms()
+        self.adam_step += 1
+        b1, b2 = self.betas
+        bc1, bc2 = 1.0 - b1 ** self.adam_step, 1.0 - b2 ** self.adam_step
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        for name, net in (('enc', self.Encoder), ('dec', self.Decoder)):
+            o = self._opt[name]
+            flat, gflat = net.flat_params()
+            L.call('zs_adam_clip', 'ZsAdam', st, p=L.ptr(flat), g=L.ptr(gflat), m=L.ptr(o['m']), v=L.ptr(o['v']),
+                   n=flat.numel(), lr=self.lr, beta1=b1, beta2=b2, eps=1e-8, bc1=bc1, bc2=bc2, sumsq=L.ptr(o['sq']),
+                   max_norm=self.max_grad_norm, write_clipped_grad=0)
+            net.mark_dirty()
+
+
+class Trainer(object):
+    def __init__(self, hps, data_loader, g_mode, enc_mode, log_dir='./log/', dtype=None, device=None):
+        self.hps = hps
+        self.data_loader = data_loader
+        self.model_kept = []
+        self.max_keep = hps.max_to_keep
+        self.logger = Logger(log_dir)
+        self.g_mode = g_mode
+        self.enc_mode = enc_mode
+        self.dtype = dtype or os.environ.get('ZS_DTYPE', 'fp32')
+        if device is None:
+            if not torch.cuda.is_available():
+                raise L.ZsError('zs_amd.Trainer needs an MI355X (torch.cuda.is_available() is False); no CPU fallback')
+            device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+        self.device = torch.device(device)
+        self.log_every = int(os.environ.get('ZS_LOG_EVERY', '1'))
+        self.build_model()
+
+    # ---- model (trainer.py:48-98) -------------------------------------------------------------
+    def build_model(self):
+        hps, ns = self.hps, self.hps.ns
+        dev, dt = self.device, self.dtype
+        self.Encoder = Encoder(ns=ns, dp=hps.enc_dp, enc_size=hps.enc_size, seg_len=hps.seg_len, enc_mode=self.enc_mode,
+                               dtype=dt).to(dev)
+        self.Decoder = Decoder(ns=ns, c_in=hps.enc_size, c_h=hps.emb_size, c_a=hps.n_speakers, seg_len=hps.seg_len,
+                               dtype=dt).to(dev)
+        if self.g_mode == 'naive':
+            self.Generator = Decoder(ns=ns, c_in=hps.enc_size, c_h=hps.emb_size, c_a=hps.n_speakers, seg_len=hps.seg_len,
+                                     dtype=dt).to(dev)
+        elif self.g_mode in ('targeted', 'targeted_residual'):
+            self.Generator = Decoder(ns=ns, c_in=hps.enc_size, c_h=hps.emb_size, c_a=hps.n_target_speakers, seg_len=hps.seg_len,
+                                     output_mask=(self.g_mode == 'targeted_residual'), dtype=dt).to(dev)
+        elif self.g_mode in ('enhanced', 'spectrogram', 'tacotron'):
+            raise NotImplementedError('g_mode %r (stage-2 generator) is outside the MI355X hot path' % self.g_mode)
+        else:
+            raise NotImplementedError('Invalid Generator mode!')
+        self.ae = AEStep(self.Encoder, self.Decoder, lr=hps.lr, betas=(0.5, 0.9), max_grad_norm=hps.max_grad_norm)
+        self.testing_shift_c = None
+
+    def reset_keep(self):
+        self.model_kept = []
+
+    # ---- checkpoints (trainer.py:103-168) -----------------------------------------------------
+    def save_model(self, model_path, name, iteration, model_all=True):
+        all_model = {
+            'encoder': self.Encoder.state_dict(),
+            'decoder': self.Decoder.state_dict(),
+            'generator': self.Generator.state_dict(),
+        }
+        all_model = {k: {n: t.detach().cpu().clone() for n, t in sd.items()} for k, sd in all_model.items()}
+        new_model_path = '{}-{}-{}'.format(model_path, name, iteration)
+        torch.save(all_model, new_model_path)
+        self.model_kept.append(new_model_path)
+        if len(self.model_kept) >= self.max_keep:
+            os.remove(self.model_kept[0])
+            self.model_kept.pop(0)
+
+    def load_model(self, model_path, load_model_list, verbose=True, clf_path=None):
+        if verbose:
+            print('[Trainer] - load model from {}'.format(model_path))
+        load_model_list = load_model_list.split(', ')
+        all_model = torch.load(model_path, map_location='cpu', weights_only=True)
+        if verbose:
+            print('[Trainer] - ', end='')
+        for key, net, tag in (('encoder', self.Encoder, 'encoder'), ('decoder', self.Decoder, 'decoder'),
+                              ('generator', self.Generator, 'generator')):
+            if key in load_model_list:
+                try:
+                    net.load_state_dict(all_model[key])
+                    if verbose:
+                        print('[%s], ' % tag, end='')
+                except Exception as e:                                   # reference: bare except, prints [x - X]
+                    print('[%s - X] (%s), ' % (tag, type(e).__name__), end='')
+        if verbose:
+            print('Loaded!')
+
+    # ---- inference (trainer.py:180-228) -------------------------------------------------------
+    def set_eval(self):
+        self.testing_shift_c = torch.tensor([int(self.hps.n_speakers - self.hps.n_target_speakers)], device=self.device)
+        self.Encoder.eval()
+        self.Decoder.eval()
+        self.Generator.eval()
+
+    def test_step(self, x, c, enc_only=False, verbose=True, U=None, G=None):
+        self.set_eval()
+        x = x.to(self.device).permute(0, 2, 1)
+        c = c.to(self.device)
+        enc, _ = self.Encoder(x, U=U, G=G)
+        x_dec = self.Decoder(enc, c)
+        if not enc_only:
+            if verbose:
+                print('Testing with Autoencoder + Generator, encoding: ', enc.cpu().numpy())
+            if self.g_mode != 'naive' and int((c - self.testing_shift_c)[0]) not in range(self.hps.n_target_speakers):
+                raise RuntimeError('This generator can only convert to target speakers!')
+            if self.g_mode == 'naive':
+                x_dec = x_dec + self.Generator(enc, c)
+            elif self.g_mode == 'targeted':
+                x_dec = x_dec + self.Generator(enc, c - self.testing_shift_c)
+            elif self.g_mode == 'targeted_residual':
+                x_dec = (x_dec * 1.0) + (1.0 * x_dec * self.Generator(enc, c - self.testing_shift_c))
+            else:
+                raise NotImplementedError('Invalid Generator mode!')
+        elif verbose:
+            print('Testing with Autoencoder only, encoding: ', enc.cpu().numpy())
+        return x_dec.cpu().numpy(), enc.cpu().numpy()
+
+    def encoder_test_step(self, x, U=None, G=None):
+        self.set_eval()
+        x = x.to(self.device).permute(0, 2, 1)
+        enc, _ = self.Encoder(x, U=U, G=G)
+        return enc.cpu().numpy()
+
+    # ---- training pieces (trainer.py:238-254) --------------------------------------------------
+    def permute_data(self, data, load_mel=False):
+        C = data[0].to(self.device, non_blocking=True)
+        X = data[1].to(self.device, non_blocking=True).permute(0, 2, 1)
+        return C, X
+
+    def encode_step(self, x):
+        return self.Encoder(x)
+
+    def decode_step(self, enc, c):
+        return self.Decoder(enc, c)
+
+    def ae_step(self, x_btf, c, **kw):
+        """One fused --train_ae iteration; see AEStep.step."""
+        return self.ae.step(x_btf, c, **kw)
+
+    # ---- the loop (trainer.py:316-347) -----------------------------------------------------------
+    def train(self, model_path, flag='train', mode='train', target_guided=False):
+        hps = self.hps
+        if mode != 'pretrain_AE':
+            raise NotImplementedError("mode %r is outside the MI355X hot path this build covers ('pretrain_AE' = --train_ae)" % mode)
+        is_main = parallel.rank() == 0
+        for iteration in range(hps.enc_pretrain_iters):
+            data = next(self.data_loader)
+            c = data[0].to(self.device, non_blocking=True)
+            x = data[1].to(self.device, non_blocking=True).float().contiguous()          # [B, seg_len, 513]
+            loss_t = self.ae_step(x, c)
+            if (iteration % self.log_every == 0) or (iteration + 1 == hps.enc_pretrain_iters):
+                loss_rec = loss_t.item()                                                  # the only host sync
+                info = {f'{flag}/pre_loss_rec': loss_rec}
+                slot_value = (iteration + 1, hps.enc_pretrain_iters) + tuple(info.values())
+                if is_main:
+                    print('pre_AE:[%06d/%06d], loss_rec=%.3f' % slot_value, end='\r')
+                    if iteration % 100 == 0:
+                        for tag, value in info.items():
+                            self.logger.scalar_summary(tag, value, iteration + 1)
+            if (iteration + 1) % 1000 == 0 and is_main:
+                self.save_model(model_path, 'ae', iteration + 1)
+        if is_main:
+            print()
