@@ -1,0 +1,223 @@
+"""bench.py -- throughput of the --train_ae step (BASELINE.json metric) on N MI355X GPUs.
+
+  python bench.py --gpus N --steps K --warmup W [--dtype bf16|fp32] [--batch 256] [--no-cpu-baseline]
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+A "step" is one pass of the hot path over one batch of synthetic segments resident in HBM: Encoder fwd,
+Decoder fwd, L1, full backward, per-net clip, Adam (dropout and Gumbel noise ON, nothing skipped).
+Workload = BASELINE.json configs[1]: english hps, seg_len=128, enc_size=1024, emb_size=1024, 102 speakers,
+513-bin frames, batch 256 per GPU.  One JSON line is printed by rank 0.
+
+roofline: the dominant kernel is gemm_conv_kernel (implicit-GEMM conv / linear forward + data gradient).
+  achieved = algorithmic FLOPs of those launches (2*M*Cout*Cin*k per call, unpadded sizes) / their summed
+  duration, measured with HIP events on the launch stream during the timed steps; peak = dense MFMA peak
+  of the dtype (bf16 2.5 PFLOP/s, exact-fp32 157.3 TFLOP/s; MI355X_MICROARCH.md).
+cpu_baseline: the oracle (CPU port of the reference, oracle/zs_oracle.py) timed on the host cores on a bounded
+  sample of the same workload (full-size model, reference batch 16), rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--dtype', default=os.environ.get('ZS_BENCH_DTYPE', 'bf16'))
+    ap.add_argument('--batch', type=int, default=256)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-events', action='store_true')
+    return ap.parse_args()
+
+
+T0 = time.time()
+
+
+def log(msg):
+    sys.stderr.write('[bench %7.1fs] %s\n' % (time.time() - T0, msg))
+    sys.stderr.flush()
+
+
+def cpu_share():
+    """CPU threads this process may really use: min(affinity, cgroup quota), capped by ZS_CPU_THREADS."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get('ZS_CPU_THREADS', '16'))))
+
+
+def cpu_baseline(seg_len, F, E, ch, nspk, steps=3, batch=16):
+    """Oracle train_ae step on the host cores (bounded sample).  Returns dict for the JSON line."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import zs_oracle as O      # checker / baseline only
+    torch.manual_seed(0)
+    cores = cpu_share()
+    torch.set_num_threads(cores)
+    log('cpu_baseline: %d threads' % cores)
+    # random-init weights of the reference architecture, through torch.nn containers (names = reference state_dict)
+    from zs_amd.model import Decoder, Encoder
+    enc = Encoder(ns=0.01, dp=0.5, enc_size=E, seg_len=seg_len, enc_mode='multilabel_binary')
+    dec = Decoder(ns=0.01, c_in=E, c_h=ch, c_a=nspk, seg_len=seg_len)
+    esd = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    dsd = {k: v.detach().clone() for k, v in dec.state_dict().items()}
+    hp = dict(ns=0.01, enc_dp=0.5, enc_size=E, seg_len=seg_len)
+    tr = O.TrainAE(esd, dsd, hp, lr=1e-4, max_grad_norm=5.0)
+    x = torch.rand(batch, F, seg_len) * (1 - 1e-8) + 1e-8
+    c = torch.randint(0, nspk, (batch,))
+    t0 = time.perf_counter()
+    tr.step(x, c)                                 # warm-up
+    log('cpu_baseline: warm-up step %.2f s' % (time.perf_counter() - t0))
+    ts = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        tr.step(x, c)
+        ts.append(time.perf_counter() - t0)
+        log('cpu_baseline: step %.2f s' % ts[-1])
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {'value': batch * seg_len / med, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d train_ae steps of %d x %d-frame segments (full-size model, fp32), median %.3f s/step' % (steps, batch, seg_len, med)}
+
+
+class KernelEvents(object):
+    """HIP-event timing of every gemm_conv launch made through ConvLayer.fwd / ConvLayer.dgrad."""
+
+    def __init__(self):
+        self.pairs = []      # (start, end, flops)
+        self.enabled = False
+
+    def install(self):
+        from zs_amd import layers
+        ke = self
+        ofwd, odgrad = layers.ConvLayer.fwd, layers.ConvLayer.dgrad
+
+        def fwd(self, A, *a, **kw):
+            if not ke.enabled:
+                return ofwd(self, A, *a, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = ofwd(self, A, *a, **kw)
+            e.record()
+            ke.pairs.append((s, e, 2.0 * A.B * self.t_out(A.T) * self.Cout * self.Cin * self.k))
+            return r
+
+        def dgrad(self, dY, T_x, out, *a, **kw):
+            if not ke.enabled:
+                return odgrad(self, dY, T_x, out, *a, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = odgrad(self, dY, T_x, out, *a, **kw)
+            e.record()
+            ke.pairs.append((s, e, 2.0 * dY.B * dY.T * self.Cout * self.Cin * self.k))
+            return r
+
+        layers.ConvLayer.fwd, layers.ConvLayer.dgrad = fwd, dgrad
+
+    def summary(self):
+        tot_ms = sum(s.elapsed_time(e) for s, e, _ in self.pairs)
+        tot_fl = sum(f for _, _, f in self.pairs)
+        return tot_fl, tot_ms, len(self.pairs)
+
+
+def main():
+    args = parse()
+    import zs_amd  # noqa: F401
+    from zs_amd import parallel
+    from zs_amd.model import Decoder, Encoder
+    from zs_amd.trainer import AEStep
+    import torch.distributed as dist
+
+    torch.set_num_threads(cpu_share())
+    rank, world, local = parallel.init_from_env('nccl')
+    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    seg_len, F, E, ch, nspk, B = 128, 513, 1024, 1024, 102, args.batch
+    torch.manual_seed(1234 + rank)
+    enc = Encoder(ns=0.01, dp=0.5, enc_size=E, seg_len=seg_len, enc_mode='multilabel_binary', dtype=args.dtype).to(dev)
+    dec = Decoder(ns=0.01, c_in=E, c_h=ch, c_a=nspk, seg_len=seg_len, dtype=args.dtype).to(dev)
+    if world > 1:                                      # identical initial weights on every rank
+        for net in (enc, dec):
+            dist.broadcast(net.flat_params()[0], src=0)
+            net.mark_dirty()
+    ae = AEStep(enc, dec, lr=1e-4, max_grad_norm=5.0)
+    g = torch.Generator().manual_seed(99 + rank)       # distinct per-rank data
+    x = (torch.rand(B, seg_len, F, generator=g) * (1 - 1e-8) + 1e-8).to(dev)
+    c = torch.randint(0, nspk, (B,), generator=g).to(dev)
+
+    ke = KernelEvents()
+    if not args.no_kernel_events:
+        ke.install()
+    log('model built (%s, B=%d), warm-up' % (args.dtype, B))
+    for i in range(args.warmup):
+        ae.step(x, c)
+        torch.cuda.synchronize()
+        log('warm-up step %d done, loss %.4f' % (i, ae._loss.item()))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ke.enabled = not args.no_kernel_events
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ae.step(x, c)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ke.enabled = False
+    log('timed %d steps: %.3f s' % (args.steps, dt))
+    loss = float(ae._loss.item())
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return
+    frames = float(B) * seg_len * args.steps * world
+    value = frames / dt
+    out = {
+        'metric': 'mel-frames/sec (train_ae, seg_len=128, enc_size=1024)', 'value': value, 'unit': 'frames/s',
+        'per_gpu': value / world, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': 'train_ae english hps seg_len=128 enc_size=1024 emb_size=1024 n_speakers=102 F=513, batch=%d/GPU, '
+                               'dropout+Gumbel on, fwd+bwd+clip+Adam' % B, 'global_batch': B * world, 'parallelism': 'dp%d' % world},
+        'final_loss': loss,
+    }
+    peak = 2500.0 if args.dtype == 'bf16' else 157.3
+    if ke.pairs:
+        fl, ms, n = ke.summary()
+        ach = fl / (ms * 1e-3) / 1e12
+        out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+                           'kernel': 'gemm_conv_kernel<%s>' % ('bf16' if args.dtype == 'bf16' else 'float'),
+                           'launches_timed': n, 'avg_launch_ms': ms / n, 'avg_launch_gflop': fl / n / 1e9,
+                           'share_of_step': ms / (1e3 * dt)}
+    else:
+        out['roofline'] = {'bound': 'mfma', 'achieved': None, 'peak': peak, 'unit': 'TFLOP/s', 'frac': None, 'traffic': None}
+    out['step_tflops'] = 180.7e6 * value / 1e12          # 180.7 MFLOP per frame for the whole step
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(seg_len, F, E, ch, nspk)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -26,7 +26,9 @@ def load_golden(name):
 
 def sub_sd(d, prefix):
     import torch
-    return {k[len(prefix):]: torch.from_numpy(v) for k, v in d.items() if k.startswith(prefix)}
+    # 'enc.<T>' / 'x_dec.<T>' style keys are data vectors, not parameters
+    return {k[len(prefix):]: torch.from_numpy(v) for k, v in d.items()
+            if k.startswith(prefix) and not k[len(prefix):].isdigit()}
 
 
 @pytest.fixture(scope='session')

@@ -107,24 +107,34 @@ __global__ __launch_bounds__(NT, 2) void gemm_conv_kernel(const ZsGemmConv p) {
   for (int i = 0; i < 4; ++i) wrow[i] = W + (int64_t)(n0 + r0 + 32 * i) * p.ldw + seg * EPS;
 
   const int nk = (int)(p.ldw / KC);
-  uint4 va[4], vb[4];
+  // staging registers are individually named (arrays captured by the loader lambdas were demoted to
+  // scratch memory by hipcc: 8 scratch accesses per K chunk)
+  uint4 va0, va1, va2, va3, vb0, vb1, vb2, vb3;
+#define ZS_LOAD_A(i, dst)                                                                             \
+  {                                                                                                   \
+    const bool ok = aoff[i] >= 0; /* branch-free: load row 0 for a zero row, then select */          \
+    const uint4 v = *reinterpret_cast<const uint4*>(A + (ok ? aoff[i] : (int64_t)0) + ci);            \
+    dst.x = ok ? v.x : 0u; dst.y = ok ? v.y : 0u; dst.z = ok ? v.z : 0u; dst.w = ok ? v.w : 0u;       \
+  }
   auto gload = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      va[i] = (aoff[i] >= 0) ? *reinterpret_cast<const uint4*>(A + aoff[i] + ci) : make_uint4(0, 0, 0, 0);
-      vb[i] = *reinterpret_cast<const uint4*>(wrow[i] + (int64_t)kt * KC);
-    }
+    ZS_LOAD_A(0, va0) ZS_LOAD_A(1, va1) ZS_LOAD_A(2, va2) ZS_LOAD_A(3, va3)
+    vb0 = *reinterpret_cast<const uint4*>(wrow[0] + (int64_t)kt * KC);
+    vb1 = *reinterpret_cast<const uint4*>(wrow[1] + (int64_t)kt * KC);
+    vb2 = *reinterpret_cast<const uint4*>(wrow[2] + (int64_t)kt * KC);
+    vb3 = *reinterpret_cast<const uint4*>(wrow[3] + (int64_t)kt * KC);
     ci += KC;                                  // advance this thread's K cursor to the next chunk
     bool moved = false;
     while (ci >= cin_pad) { ci -= cin_pad; ++tap; moved = true; }
     if (moved) set_tap();
   };
+#undef ZS_LOAD_A
   auto swrite = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<uint4*>(sA + buf * TILE_BYTES + (r0 + 32 * i) * PITCH + seg * 16) = va[i];
-      *reinterpret_cast<uint4*>(sB + buf * TILE_BYTES + (r0 + 32 * i) * PITCH + seg * 16) = vb[i];
-    }
+    unsigned char* pa = sA + buf * TILE_BYTES + r0 * PITCH + seg * 16;
+    unsigned char* pb = sB + buf * TILE_BYTES + r0 * PITCH + seg * 16;
+    *reinterpret_cast<uint4*>(pa) = va0; *reinterpret_cast<uint4*>(pa + 32 * PITCH) = va1;
+    *reinterpret_cast<uint4*>(pa + 64 * PITCH) = va2; *reinterpret_cast<uint4*>(pa + 96 * PITCH) = va3;
+    *reinterpret_cast<uint4*>(pb) = vb0; *reinterpret_cast<uint4*>(pb + 32 * PITCH) = vb1;
+    *reinterpret_cast<uint4*>(pb + 64 * PITCH) = vb2; *reinterpret_cast<uint4*>(pb + 96 * PITCH) = vb3;
   };
 
   f32x16 acc[2][2];
