@@ -1,0 +1,211 @@
+"""CPU tests: the C ABI library loads and exports every declared symbol with the declared struct layouts,
+the product path fails loudly without a GPU, and the host logic (hps, dataloader, segmenter, CLI, data-parallel
+reducer over gloo) behaves like the reference's."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import zs_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    import zs_amd  # noqa: F401
+    from zs_amd import _lib, build
+    build.build(verbose=False)
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(lib):
+    L = lib.lib()
+    assert len(lib.FUNCTIONS) >= 24
+    missing = [f for f in lib.FUNCTIONS if not hasattr(L, f)]
+    assert not missing, missing
+    assert L.zs_abi_version() == lib.ENUMS['ZS_ABI_VERSION']
+
+
+def test_struct_layouts_match_the_c_compiler(lib, tmp_path):
+    names = list(lib.STRUCTS)
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){\n' % lib.HEADER
+    for n in names:
+        src += 'printf("%s %%zu\\n", sizeof(%s));\n' % (n, n)
+        for f, _ in lib._STRUCT_FIELDS[n]:
+            src += 'printf("%s.%s %%zu\\n", offsetof(%s,%s));\n' % (n, f, n, f)
+    src += 'return 0;}\n'
+    c = tmp_path / 'sz.c'
+    c.write_text(src)
+    subprocess.check_call(['gcc', str(c), '-o', str(tmp_path / 'sz')])
+    for line in subprocess.check_output([str(tmp_path / 'sz')]).decode().split('\n'):
+        if not line:
+            continue
+        k, v = line.split()
+        if '.' in k:
+            n, f = k.split('.')
+            assert getattr(lib.STRUCTS[n], f).offset == int(v), k
+        else:
+            assert ctypes.sizeof(lib.STRUCTS[k]) == int(v), k
+
+
+def test_invalid_calls_return_errors_not_crashes(lib):
+    with pytest.raises(lib.ZsError, match='null operand'):
+        lib.call('zs_gemm_conv', 'ZsGemmConv', 0, dtype=0)
+    with pytest.raises(lib.ZsError):
+        lib.call('zs_instnorm_fwd', 'ZsInstNormFwd', 0, dtype=7)
+    assert 'zs_' in lib.last_error()
+
+
+def test_no_cpu_fallback():
+    import zs_amd  # noqa: F401
+    from zs_amd import _lib
+    from zs_amd.layers import Ctx
+    from zs_amd.model import Encoder
+    if torch.cuda.is_available():
+        pytest.skip('has GPU')
+    with pytest.raises(_lib.ZsError, match='no CPU'):
+        Ctx('cpu')
+    enc = Encoder(c_in=80, c_h1=16, c_h2=32, c_h3=16, enc_size=8, seg_len=128, enc_mode='multilabel_binary')
+    with pytest.raises(_lib.ZsError, match='no CPU fallback'):
+        enc(torch.rand(1, 80, 16))
+    with pytest.raises(NotImplementedError):
+        Encoder(enc_mode='nonsense')
+    src = open(os.path.join(ROOT, 'zerospeech-tts-without-t_amd', 'model.py')).read() + \
+        open(os.path.join(ROOT, 'zerospeech-tts-without-t_amd', 'engine.py')).read() + \
+        open(os.path.join(ROOT, 'zerospeech-tts-without-t_amd', 'trainer.py')).read() + \
+        open(os.path.join(ROOT, 'zerospeech-tts-without-t_amd', 'convert.py')).read()
+    assert 'zs_oracle' not in src and 'oracle' not in src.replace('oracle/', '')      # product never imports the oracle
+
+
+def test_hps_surface():
+    from zs_amd.hps import HPS_KEYS, Hps, hp
+    assert len(HPS_KEYS) == 32
+    h = Hps(os.path.join(ROOT, 'hps', 'zerospeech_english.json')).get_tuple()
+    assert (h.seg_len, h.enc_size, h.emb_size, h.n_speakers, h.batch_size, h.lr, h.max_grad_norm) == (128, 6, 1024, 102, 16, 1e-4, 5)
+    assert (hp.sr, hp.n_fft, hp.hop_length, hp.win_length, hp.n_iter, hp.preemphasis, hp.max_db, hp.ref_db) == \
+        (16000, 1024, 200, 800, 300, .97, 100, 20)
+    d = dict(h._asdict())
+    d.pop('lr')
+    p = os.path.join(ROOT, 'tests', '_tmp_hps.json')
+    try:
+        json.dump(d, open(p, 'w'))
+        with pytest.raises(TypeError):
+            Hps(p)
+        d['lr'] = 1e-4; d['extra'] = 1
+        json.dump(d, open(p, 'w'))
+        with pytest.raises(TypeError):
+            Hps(p)
+    finally:
+        os.remove(p)
+
+
+def test_dataloader_contract():
+    from zs_amd.dataloader import DataLoader, SyntheticDataset
+    ds = SyntheticDataset(40, seg_len=16, n_bins=513, n_speakers=7, seed=1)
+    dl = DataLoader(ds, batch_size=16)
+    c, x = next(dl)
+    assert c.dtype == torch.int64 and c.shape == (16,) and x.dtype == torch.float32 and x.shape == (16, 16, 513)
+    assert x.min() >= 1e-8 and x.max() <= 1.0
+    assert dl.index == 16
+    next(dl)                       # index 16 + 2*16 >= 40 -> wraps to 0 (dataloader.py:48-49)
+    assert dl.index == 0
+    c2, x2 = next(dl)
+    assert torch.equal(c, c2) and torch.equal(x, x2)
+    dl16 = DataLoader(SyntheticDataset(16, seg_len=8), batch_size=16)   # BASELINE config 1: one batch re-served forever
+    a = next(dl16); b = next(dl16)
+    assert torch.equal(a[1], b[1]) and dl16.index == 0
+
+
+def test_segmenter_matches_oracle_and_text_format(tmp_path):
+    from zs_amd import convert
+    for n in (9, 100, 128, 129, 255, 256, 257, 300, 383, 384, 385, 700, 1000):
+        if n <= 128:
+            continue
+        assert convert.fragments(n, 128) == O.fragment_plan(n, 128)[1], n
+    with pytest.raises(RuntimeError, match='too short'):
+        convert.fragments(129, 200)                      # one piece of 128 frames < seg_len 200 at idx 0
+    enc = np.array([[1., 0., 1., 1.], [0., 0., 0., 1.]])
+    convert.write_encodings(str(tmp_path / 'e.txt'), enc)
+    assert open(str(tmp_path / 'e.txt')).read() == '1 0 1 1\n0 0 0 1\n' == O.encodings_text(enc)
+    assert convert.parse_encodings(enc) == ['1 0 1 1', '0 0 0 1']
+    rng = np.random.RandomState(0)
+    y = np.concatenate([np.zeros(3000), rng.randn(8000) * 0.1, np.zeros(5000)])
+    a, ia = convert.trim(y)
+    b, ib = O.trim(y)
+    assert ia == ib and np.array_equal(a, b) and 0 < len(a) < len(y)
+    convert.write_wav(str(tmp_path / 'w.wav'), np.array([0.0, 0.5, -0.5, 1.0], dtype=np.float32), 16000)
+    import wave
+    with wave.open(str(tmp_path / 'w.wav')) as f:
+        assert (f.getframerate(), f.getsampwidth(), f.getnchannels(), f.getnframes()) == (16000, 2, 1, 4)
+
+
+def test_cli_surface(capsys):
+    sys.path.insert(0, ROOT)
+    import main
+    args, hps = main.argument_runner(['--train_ae', '--hps_path', os.path.join(ROOT, 'hps', 'zerospeech_english_1024.json')])
+    assert args.train_ae and args.g_mode == 'targeted_residual' and args.enc_mode == 'multilabel_binary' and hps.enc_size == 1024
+    args, _ = main.argument_runner(['--test', '--enc_only', '--dataset', 'surprise', '--hps_path',
+                                    os.path.join(ROOT, 'hps', 'zerospeech_surprise.json')])
+    assert args.ckpt_dir == './ckpt_surprise' and args.dataset_path == './data/dataset_surprise.hdf5' and \
+        args.synthesis_list == './data/surprise/synthesis.txt' and args.sub_result_dir == './surprise/'
+    with pytest.raises(NotImplementedError):
+        main.main(['--train_p', '--hps_path', os.path.join(ROOT, 'hps', 'zerospeech_english.json')])
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import zs_amd  # noqa: F401
+    from zs_amd import parallel
+    from conftest import load_golden, sub_sd
+    torch.set_num_threads(1)
+    parallel.init_from_env('gloo')
+    d, m = load_golden('train_f80.npz')
+    g = torch.Generator().manual_seed(0)
+    B = 4
+    x = torch.rand(B, m['c_in'], 32, generator=g)
+    c = torch.randint(0, m['n_spk'], (B,), generator=g)
+    G = O.gumbel_from_uniform(torch.rand(B, 4, m['enc_size'], 2, generator=g))
+    hp = dict(ns=m['ns'], enc_dp=0.0, enc_size=m['enc_size'], seg_len=m['seg_len'])
+    lo, hi = parallel.shard_range(B, rank, world)
+    _, (ge, gd), _, _ = O.train_ae_grads(sub_sd(d, 'enc0.'), sub_sd(d, 'dec0.'), x[lo:hi], c[lo:hi], hp, G=G[lo:hi])
+    flat = torch.cat([v.reshape(-1) for v in list(ge.values()) + list(gd.values())])
+    red = parallel.GradReducer(bucket_bytes=64 << 10)          # several buckets
+    red.start(flat)
+    red.finish()
+    if rank == 0:
+        _, (fe, fd), _, _ = O.train_ae_grads(sub_sd(d, 'enc0.'), sub_sd(d, 'dec0.'), x, c, hp, G=G)
+        full = torch.cat([v.reshape(-1) for v in list(fe.values()) + list(fd.values())])
+        q.put(((flat - full).abs().max().item(), full.abs().max().item(), parallel.world_size()))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_data_parallel_gradient_average_gloo():
+    """world_size 2 over gloo: the averaged per-rank gradients equal the single-process global-batch gradient
+    (segments are independent: InstanceNorm is per sample)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    err, scale, world = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert world == 2 and err <= 2e-5 * scale, (err, scale)
+
+
+def test_shard_range():
+    from zs_amd.parallel import shard_range
+    parts = [shard_range(10, r, 4) for r in range(4)]
+    assert parts == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert sum(b - a for a, b in parts) == 10

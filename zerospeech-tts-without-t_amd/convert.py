@@ -1,0 +1,270 @@
+"""Inference / resynthesis surface of the reference's convert.py (lines 36-265, 303-360).
+
+convert() / encode() reproduce the reference's fragment rule exactly (MIN_LEN zero padding, `spec[idx:-1]`
+tail that drops the last frame, tails shorter than seg_len skipped, RuntimeError for a too-short input),
+call Trainer.test_step / encoder_test_step per fragment and concatenate.  spectrogram2wav() /
+griffin_lim() run the 300-iteration Griffin-Lim on the MI355X (zs_gl_* kernels: 1024-point FFTs in LDS),
+batched over utterances by griffin_lim_batch(); de-preemphasis on the device, librosa.effects.trim restated
+on the host (librosa itself is not required).  Utterances are independent: multi-GPU = replicas over a
+sharded utterance list (zs_amd.parallel.shard_range), no collective.
+"""
+import ctypes
+import glob
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .hps import Hps, hp
+
+MIN_LEN = 9
+
+
+# ---------------------------------------------------------------------------------------------------
+# vocoder (convert.py:39-62)
+# ---------------------------------------------------------------------------------------------------
+
+def _device():
+    if not torch.cuda.is_available():
+        raise L.ZsError('zs_amd.convert needs an MI355X; there is no CPU fallback')
+    return torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+
+
+def griffin_lim_batch(mags, n_iter=None, device=None):
+    """mags: list of real [513, T_i] amplitude spectrograms.  Returns list of float32 wavs of 200*(T_i-1) samples.
+    X = S (zero phase); n_iter x { x = istft(X); E = stft(x); X = S * E / max(1e-8, |E|) }; x = istft(X)."""
+    n_iter = hp.n_iter if n_iter is None else n_iter
+    dev = device or _device()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    n = len(mags)
+    lens = [int(m.shape[1]) for m in mags]
+    if min(lens) < 2:
+        raise ValueError('griffin_lim needs at least 2 frames')
+    Tm = max(lens)
+    mag = torch.zeros(n, Tm, 513, dtype=torch.float32, device=dev)
+    for i, m in enumerate(mags):
+        t = m if torch.is_tensor(m) else torch.as_tensor(np.asarray(m, dtype=np.float32))
+        mag[i, :lens[i]] = t.to(dev, torch.float32).t()
+    lengths = torch.tensor(lens, dtype=torch.int32, device=dev)
+    spec = torch.zeros(n, Tm, 513, 2, dtype=torch.float32, device=dev)
+    spec[..., 0] = mag
+    wav_ld = 200 * (Tm - 1)
+    wav = torch.zeros(n, wav_ld, dtype=torch.float32, device=dev)
+    frames = torch.empty(n, Tm, 1024, dtype=torch.float32, device=dev)
+    ist = dict(spec=L.ptr(spec), mag=L.ptr(mag), lengths=L.ptr(lengths), n_utt=n, T_max=Tm, wav=L.ptr(wav), wav_ld=wav_ld,
+               frames_ws=L.ptr(frames))
+    stf = dict(wav=L.ptr(wav), wav_ld=wav_ld, mag=L.ptr(mag), lengths=L.ptr(lengths), n_utt=n, T_max=Tm, spec=L.ptr(spec))
+    for _ in range(n_iter):
+        L.call('zs_gl_istft', 'ZsGlIstft', st, **ist)
+        L.call('zs_gl_stft_project', 'ZsGlStft', st, **stf)
+    L.call('zs_gl_istft', 'ZsGlIstft', st, **ist)
+    return wav, lengths, lens
+
+
+def griffin_lim(spectrogram, n_iter=None):
+    """convert.py:39-52 for one [513, T] amplitude spectrogram."""
+    wav, _, lens = griffin_lim_batch([spectrogram], n_iter=n_iter)
+    return wav[0, :200 * (lens[0] - 1)].cpu().numpy()
+
+
+def trim(wav, top_db=60, frame_length=2048, hop_length=512):
+    """librosa.effects.trim defaults restated (RMS of centred frames, dB relative to the max)."""
+    y = np.asarray(wav, dtype=np.float64)
+    if len(y) == 0:
+        return y, (0, 0)
+    yp = np.pad(y, frame_length // 2, mode='reflect')
+    n_frames = 1 + (len(yp) - frame_length) // hop_length
+    idx = np.arange(frame_length)[None, :] + hop_length * np.arange(n_frames)[:, None]
+    mse = np.mean(yp[idx] ** 2, axis=1)
+    db = 10.0 * np.log10(np.maximum(1e-10, mse)) - 10.0 * np.log10(np.maximum(1e-10, np.max(mse)))
+    nz = np.flatnonzero(db > -top_db)
+    if nz.size == 0:
+        return y[0:0], (0, 0)
+    start, end = int(nz[0]) * hop_length, min(len(y), (int(nz[-1]) + 1) * hop_length)
+    return y[start:end], (start, end)
+
+
+def spectrogram2wav_batch(mags_tf, n_iter=None, do_trim=True):
+    """Batched spectrogram2wav (convert.py:55-62): list of [T_i, 513] normalised magnitudes -> list of float32 wavs."""
+    dev = _device()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    amps = []
+    for m in mags_tf:
+        t = torch.as_tensor(np.ascontiguousarray(np.asarray(m, dtype=np.float32))).to(dev)
+        a = torch.empty_like(t)
+        L.check(L.lib().zs_gl_denormalize(L.ptr(t), L.ptr(a), t.numel(), st), 'zs_gl_denormalize')
+        amps.append(a.t())                                    # [513, T]
+    wav, lengths, lens = griffin_lim_batch(amps, n_iter=n_iter, device=dev)
+    L.check(L.lib().zs_gl_deemphasis(L.ptr(wav), wav.shape[1], L.ptr(lengths), len(lens), float(hp.preemphasis), st),
+            'zs_gl_deemphasis')                               # signal.lfilter([1], [1, -0.97], wav)
+    w = wav.cpu().numpy()
+    out = []
+    for i, T in enumerate(lens):
+        y = w[i, :200 * (T - 1)]
+        if do_trim:
+            y, _ = trim(y)
+        out.append(np.asarray(y, dtype=np.float32))
+    return out
+
+
+def spectrogram2wav(mag, n_iter=None):
+    return spectrogram2wav_batch([mag], n_iter=n_iter)[0]
+
+
+# ---------------------------------------------------------------------------------------------------
+# fragment drivers (convert.py:70-221)
+# ---------------------------------------------------------------------------------------------------
+
+def convert_x(x, c, trainer, enc_only, verbose=False):
+    c_var = torch.from_numpy(np.array([c]))
+    tensor = torch.from_numpy(np.expand_dims(x, axis=0)).type(torch.FloatTensor)
+    converted, enc = trainer.test_step(tensor, c_var, enc_only=enc_only, verbose=verbose)
+    return converted.squeeze(axis=0).transpose((1, 0)), enc.squeeze(axis=0).transpose((1, 0))
+
+
+def encode_x(x, trainer):
+    tensor = torch.from_numpy(np.expand_dims(x, axis=0)).type(torch.FloatTensor)
+    return trainer.encoder_test_step(tensor).squeeze(axis=0).transpose((1, 0))
+
+
+def get_trainer(hps_path, model_path, g_mode, enc_mode, clf_path=None):
+    from .trainer import Trainer
+    hps = Hps(hps_path).get_tuple()
+    global MIN_LEN
+    MIN_LEN = MIN_LEN if hps.enc_mode != 'gumbel_t' else hps.seg_len
+    trainer = Trainer(hps, None, g_mode, enc_mode)
+    trainer.load_model(model_path, load_model_list=hps.load_model_list, clf_path=clf_path)
+    return trainer
+
+
+def fragments(n_frames, seg_len):
+    """(start, stop) slices the reference sends through the network for an utterance of n_frames >= MIN_LEN
+    (convert.py:151-165): full seg_len pieces, then a tail `spec[idx:-1]` once idx + 2*seg_len > len; pieces
+    shorter than seg_len are skipped."""
+    out = []
+    for idx in range(0, n_frames, seg_len):
+        if idx + (seg_len * 2) > n_frames:
+            start, stop = idx, n_frames - 1
+        else:
+            start, stop = idx, idx + seg_len
+        if stop - start >= seg_len:
+            out.append((start, stop))
+        elif idx == 0:
+            raise RuntimeError('Please check if input is too short!')
+    return out
+
+
+def _pad_min(spec):
+    if len(spec) < MIN_LEN:
+        padding = np.zeros((MIN_LEN - spec.shape[0], spec.shape[1]))
+        return np.concatenate((spec, padding), axis=0), True
+    return spec, False
+
+
+def parse_encodings(encodings):
+    return [' '.join([str(int(e)) for e in enc]) for enc in encodings]
+
+
+def write_encodings(path, encodings):
+    with open(path, 'w') as file:
+        for enc in encodings:
+            for i, e in enumerate(enc):
+                file.write(str(int(e)) + (' ' if i < len(enc) - 1 else ''))
+            file.write('\n')
+
+
+def convert(trainer, seg_len, src_speaker_spec, src_speaker, tar_speaker, utt_id, speaker2id, result_dir, enc_only=True,
+            save=['wav', 'enc']):
+    src_speaker_spec, PADDED = _pad_min(src_speaker_spec)
+    if len(src_speaker_spec) <= seg_len:
+        converted_results, encodings = convert_x(src_speaker_spec, speaker2id[tar_speaker], trainer, enc_only=enc_only)
+        if PADDED:
+            encodings = encodings[:MIN_LEN // 8]
+    else:
+        converted_results, encodings = [], []
+        for a, b in fragments(len(src_speaker_spec), seg_len):
+            converted_x, enc = convert_x(src_speaker_spec[a:b], speaker2id[tar_speaker], trainer, enc_only=enc_only)
+            converted_results.append(converted_x)
+            encodings.append(enc)
+        converted_results = np.concatenate(converted_results, axis=0)
+        encodings = np.concatenate(encodings, axis=0)
+    wav_data = spectrogram2wav(converted_results)
+    if len(save) != 0:
+        wav_path = None
+        if 'wav' in save:
+            wav_path = os.path.join(result_dir, f'{tar_speaker}_{utt_id}.wav')
+            write_wav(wav_path, wav_data, hp.sr)
+        if 'enc' in save:
+            write_encodings(os.path.join(result_dir, f'{src_speaker}_{utt_id}.txt'), encodings)
+        return wav_path, len(converted_results)
+    return wav_data, encodings
+
+
+def encode(src_speaker_spec, trainer, seg_len, s_speaker=None, utt_id=None, result_dir=None, save=True):
+    if save:
+        assert result_dir is not None and s_speaker is not None and utt_id is not None
+    src_speaker_spec, PADDED = _pad_min(src_speaker_spec)
+    if len(src_speaker_spec) <= seg_len:
+        encodings = encode_x(src_speaker_spec, trainer)
+        if PADDED:
+            encodings = encodings[:MIN_LEN // 8]
+    else:
+        encodings = [encode_x(src_speaker_spec[a:b], trainer) for a, b in fragments(len(src_speaker_spec), seg_len)]
+        encodings = np.concatenate(encodings, axis=0)
+    if save:
+        write_encodings(os.path.join(result_dir, f'{s_speaker}_{utt_id}.txt'), encodings)
+    else:
+        return encodings
+
+
+def write_wav(path, wav, sr):
+    """16-bit PCM mono wav (the reference uses soundfile.write(..., 'PCM_16'), convert.py:174)."""
+    import wave
+    pcm = np.clip(np.round(np.asarray(wav, dtype=np.float64) * 32767.0), -32768, 32767).astype('<i2')
+    with wave.open(path, 'wb') as f:
+        f.setnchannels(1)
+        f.setsampwidth(2)
+        f.setframerate(sr)
+        f.writeframes(pcm.tobytes())
+
+
+def _open_h5(path):
+    try:
+        import h5py
+    except ImportError as e:
+        raise ImportError('reading %s needs h5py' % path) from e
+    return h5py.File(path, 'r')
+
+
+def test_from_list(trainer, seg_len, synthesis_list, data_path, speaker2id_path, result_dir, enc_only, flag='test', run_asr=False):
+    """convert.py:224-265 (the ASR scoring branch needs the network and is not reproduced)."""
+    with open(speaker2id_path, 'r') as f_json:
+        speaker2id = json.load(f_json)
+    feeds = []
+    with open(synthesis_list, 'r') as f:
+        for line in f.readlines():
+            line = line.split('\n')[0].split(' ')
+            feeds.append({'s_id': line[0].split('/')[1].split('_')[0], 'utt_id': line[0].split('/')[1].split('_')[1], 't_id': line[1]})
+    print('[Tester] - Number of files to be resynthesize: ', len(feeds))
+    dir_path = os.path.join(result_dir, f'{flag}/')
+    os.makedirs(dir_path, exist_ok=True)
+    with _open_h5(data_path) as f_h5:
+        for feed in feeds:
+            convert(trainer, seg_len, src_speaker_spec=f_h5[f"test/{feed['s_id']}/{feed['utt_id']}/lin"][()], src_speaker=feed['s_id'],
+                    tar_speaker=feed['t_id'], utt_id=feed['utt_id'], speaker2id=speaker2id, result_dir=dir_path, enc_only=enc_only,
+                    save=['wav'])
+
+
+def test_encode(trainer, seg_len, test_path, data_path, result_dir, flag='test'):
+    """convert.py:342-360."""
+    files = sorted(glob.glob(os.path.join(test_path, '*.wav')))
+    feeds = [{'s_id': f.split('/')[-1].split('_')[0], 'utt_id': f.split('/')[-1].split('_')[1].split('.')[0]} for f in files]
+    print('[Tester] - Number of files to encoded: ', len(feeds))
+    dir_path = os.path.join(result_dir, f'{flag}/')
+    os.makedirs(dir_path, exist_ok=True)
+    with _open_h5(data_path) as f_h5:
+        for feed in feeds:
+            encode(f_h5[f"test/{feed['s_id']}/{feed['utt_id']}/lin"][()], trainer, seg_len, s_speaker=feed['s_id'],
+                   utt_id=feed['utt_id'], result_dir=dir_path)
