@@ -116,6 +116,7 @@ typedef struct {
   int32_t inner_pad;               /* cin_pad (transpose 0) or cout_pad (transpose 1) */
   void* dst; int64_t ldw;
   int32_t n_rows, n_cols, row_offset, col_offset;
+  const int32_t* row_perm;         /* optional: output row n reads parameter row row_perm[n] (overrides co_split2) */
 } ZsPackWeight;
 int zs_pack_weight(const ZsPackWeight* p, void* stream);
 
@@ -233,6 +234,9 @@ int zs_mbv_bwd(const ZsMbvBwd* p, void* stream);
  * ([B*T][ldgi], columns dir*3H + {r,z,n}*H) comes from zs_gemm_conv.  Per time step the library
  * enqueues one grouped recurrent product (zs_gemm_conv kernel, 2 directions) and one gate kernel.
  * out[b,t, out_col + dir*H + j] = h_t.  gates saves r,z,n,(W_hn h + b_hn) for backward.
+ * Fast path (H % 32 == 0 and whh_interleaved): ONE launch per step -- a 16-rows-per-wave MFMA product whose
+ * fragments come straight from L2 (no LDS, no barrier) with the gate math fused in its epilogue.  It needs the
+ * rows of whh packed gate-interleaved per 32 hidden units: row hc*96 + g*32 + u = W_hh[g*H + hc*32 + u].
  */
 typedef struct {
   int32_t dtype;
@@ -243,6 +247,7 @@ typedef struct {
   void* out; int64_t ldo; int32_t out_col;
   void* gates; /* T dtype [B][T][2][4H] or null (inference) */
   float* work; size_t work_bytes;   /* >= zs_gru_work_bytes */
+  int32_t whh_interleaved;
 } ZsGruFwd;
 size_t zs_gru_work_bytes(int32_t B, int32_t H);
 int zs_gru_fwd(const ZsGruFwd* p, void* stream);

@@ -312,7 +312,7 @@ def test_mbv_bit_exact_and_grad(zs):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('shape', [(3, 5, 24, 16), (2, 16, 32, 32)])
+@pytest.mark.parametrize('shape', [(3, 5, 24, 16), (2, 16, 32, 32), (70, 6, 64, 64), (5, 9, 40, 96)])
 def test_gru(zs, dtype, shape):
     """Bidirectional GRU forward + BPTT + all parameter gradients vs. the oracle GRU under autograd."""
     L, layers = zs

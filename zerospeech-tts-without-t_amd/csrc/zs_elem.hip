@@ -22,7 +22,7 @@ __global__ void pack_weight_kernel(const ZsPackWeight p) {
     float v = 0.f;
     if (n < p.Cout && ci < p.Cin && tap < p.taps) {
       const int half = p.Cout >> 1;
-      const int co = p.co_split2 ? (n < half ? 2 * n : 2 * (n - half) + 1) : n;
+      const int co = p.row_perm ? p.row_perm[n] : (p.co_split2 ? (n < half ? 2 * n : 2 * (n - half) + 1) : n);
       v = p.W[(int64_t)co * p.so + (int64_t)ci * p.si + (int64_t)tap * p.sj];
     }
     stT<T>(p.dst, (int64_t)(row + p.row_offset) * p.ldw + p.col_offset + k, v);

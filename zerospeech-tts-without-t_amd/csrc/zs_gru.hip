@@ -97,6 +97,129 @@ __global__ void gru_gate_bwd_kernel(const GateBwdArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Small-M product for the recurrence: out[M, N] = A[M, K] * W[N, K]^T with M = batch (a few hundred rows).
+// One wave owns 16 rows x (16*NT16) columns; operands are loaded as MFMA fragments straight from global
+// memory (they are L2/MALL resident: h_{t-1} and W_hh are re-read every step), 16 B per lane per fragment,
+// no LDS and no barrier, so the waves of a step never wait on each other.  bf16: v_mfma_f32_16x16x32_bf16;
+// fp32: four v_mfma_f32_16x16x4_f32 per 16-byte fragment (lane q supplies k = 4q+s in step s on both sides).
+// GRU = true fuses the forward gate math: W rows are packed [r(32) | z(32) | n(32)] per 32 hidden units, so
+// a lane's accumulators (col = lane&15) of tiles {0,1}/{2,3}/{4,5} are r/z/n of the SAME (row, unit).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+struct RowGemmArgs {
+  const void* A; int64_t a_row_stride; int64_t a_gstride;
+  const void* W; int64_t ldw; int64_t w_gstride;
+  int M, N, K;
+  float* out; int64_t out_gstride;     // plain mode: fp32 [g][M][N]
+  GateFwdArgs gate;                    // GRU mode
+};
+
+template <typename T> struct Frag16;
+template <> struct Frag16<bf16_t> {
+  static constexpr int KSTEP = 32;     // elements of K per 16-byte-per-lane fragment step
+  static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x4_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Frag16<float> {
+  static constexpr int KSTEP = 16;
+  static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x4_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+};
+
+template <typename T, int NT16, bool GRU>
+__global__ __launch_bounds__(256) void rowblock_gemm_kernel(const RowGemmArgs a) {
+  constexpr int KSTEP = Frag16<T>::KSTEP;
+  constexpr int EPL = 16 / (int)sizeof(T);            // elements per lane per fragment
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, r = lane & 15;
+  const int g = blockIdx.z;
+  const int m0 = (blockIdx.y * 4 + wave) * 16;
+  if (m0 >= a.M) return;                               // whole wave out of range (no barriers in this kernel)
+  const int n0 = blockIdx.x * (16 * NT16);
+  const int row = m0 + r;
+  const bool rvalid = row < a.M;
+  const T* Arow = (const T*)a.A + (int64_t)g * a.a_gstride + (int64_t)(rvalid ? row : m0) * a.a_row_stride + q * EPL;
+  const T* Wrow = (const T*)a.W + (int64_t)g * a.w_gstride + (int64_t)(n0 + r) * a.ldw + q * EPL;
+  f32x4_t acc[NT16];
+#pragma unroll
+  for (int c = 0; c < NT16; ++c) acc[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const bool skip = GRU && (a.gate.step == 0);         // h_{-1} = 0
+  if (!skip) {
+    const int nks = a.K / KSTEP;
+    int ks = 0;
+    for (; ks + 4 <= nks; ks += 4) {                   // 4 k-steps of fragments in flight before the first MFMA
+      uint4 fa[4], fb[4][NT16];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        fa[u] = *reinterpret_cast<const uint4*>(Arow + (ks + u) * KSTEP);
+#pragma unroll
+        for (int c = 0; c < NT16; ++c) fb[u][c] = *reinterpret_cast<const uint4*>(Wrow + (int64_t)(16 * c) * a.ldw + (ks + u) * KSTEP);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!rvalid) fa[u] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NT16; ++c) Frag16<T>::mma(fa[u], fb[u][c], acc[c]);
+      }
+    }
+    for (; ks < nks; ++ks) {
+      uint4 fa = *reinterpret_cast<const uint4*>(Arow + ks * KSTEP);
+      if (!rvalid) fa = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < NT16; ++c) {
+        const uint4 fb = *reinterpret_cast<const uint4*>(Wrow + (int64_t)(16 * c) * a.ldw + ks * KSTEP);
+        Frag16<T>::mma(fa, fb, acc[c]);
+      }
+    }
+  }
+  if constexpr (!GRU) {
+    float* out = a.out + (int64_t)g * a.out_gstride;
+#pragma unroll
+    for (int c = 0; c < NT16; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 4 * q + i;
+        if (m < a.M) out[(int64_t)m * a.N + n0 + 16 * c + r] = acc[c][i];
+      }
+  } else {
+    const GateFwdArgs& ga = a.gate;
+    const int d = g, H = ga.H;
+    const int t = d == 0 ? ga.step : ga.T - 1 - ga.step;
+    const float* bh = ga.bhh + (int64_t)d * ga.bhh_gstride;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int j = blockIdx.x * 32 + hh * 16 + r;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int b = m0 + 4 * q + i;
+        if (b >= a.M) continue;
+        const T* gi = (const T*)ga.gi + ((int64_t)b * ga.T + t) * ga.ldgi + (int64_t)d * 3 * H;
+        const int64_t si = ((int64_t)d * ga.B + b) * H + j;
+        const float hp = skip ? 0.f : ga.hstate[si];
+        const float rg = 1.f / (1.f + expf(-(Elem<T>::ld(gi + j) + (acc[hh][i] + bh[j]))));
+        const float zg = 1.f / (1.f + expf(-(Elem<T>::ld(gi + H + j) + (acc[2 + hh][i] + bh[H + j]))));
+        const float hn = acc[4 + hh][i] + bh[2 * H + j];
+        const float ng = tanhf(Elem<T>::ld(gi + 2 * H + j) + rg * hn);
+        const float h = (1.f - zg) * ng + zg * hp;
+        ga.hstate[si] = h;
+        Elem<T>::st((T*)ga.out + ((int64_t)b * ga.T + t) * ga.ldo + ga.out_col + d * H + j, h);
+        if (ga.gates) {
+          T* gs = (T*)ga.gates + (((int64_t)b * ga.T + t) * 2 + d) * 4 * H;
+          Elem<T>::st(gs + j, rg); Elem<T>::st(gs + H + j, zg); Elem<T>::st(gs + 2 * H + j, ng); Elem<T>::st(gs + 3 * H + j, hn);
+        }
+      }
+    }
+  }
+}
+
 inline unsigned gate_blocks(int64_t total) {
   int64_t b = (total + NTG - 1) / NTG;
   if (b > 2048) b = 2048;
@@ -121,6 +244,28 @@ extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
   float* gh = p->work;
   float* hstate = p->work + (size_t)2 * B * 3 * H;
   const char* outb = (const char*)p->out;
+  if (p->whh_interleaved && H % 32 == 0) {
+    // one fused launch per step: recurrent product + gates (see rowblock_gemm_kernel)
+    for (int s = 0; s < T; ++s) {
+      RowGemmArgs a;
+      memset(&a, 0, sizeof(a));
+      const int sp = s > 0 ? s - 1 : 0;
+      const int64_t off0 = (int64_t)sp * p->ldo + p->out_col;                        // dir 0 reads h_{t-1} at row t-1
+      const int64_t off1 = (int64_t)(s > 0 ? T - s : T - 1) * p->ldo + p->out_col + H;   // dir 1 reads row t+1
+      a.A = outb + off0 * es; a.a_row_stride = (int64_t)T * p->ldo; a.a_gstride = off1 - off0;
+      a.W = p->whh; a.ldw = p->ldw; a.w_gstride = p->w_gstride;
+      a.M = B; a.N = 3 * H; a.K = H;
+      GateFwdArgs& g = a.gate;
+      g.gi = p->gi; g.ldgi = p->ldgi; g.gh = nullptr; g.bhh = p->bhh; g.bhh_gstride = p->bhh_gstride; g.hstate = hstate;
+      g.out = p->out; g.ldo = p->ldo; g.out_col = p->out_col; g.gates = p->gates; g.B = B; g.T = T; g.H = H; g.step = s;
+      dim3 grid(H / 32, (B + 63) / 64, 2);
+      if (p->dtype == ZS_F32) hipLaunchKernelGGL((rowblock_gemm_kernel<float, 6, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((rowblock_gemm_kernel<bf16_t, 6, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      int rc = zs_check_launch("zs_gru_fwd.step");
+      if (rc) return rc;
+    }
+    return ZS_OK;
+  }
   for (int s = 0; s < T; ++s) {
     if (s > 0) {
       ZsGemmConv g;
@@ -171,7 +316,21 @@ extern "C" int zs_gru_bwd(const ZsGruBwd* p, void* stream) {
     else hipLaunchKernelGGL(gru_gate_bwd_kernel<bf16_t>, dim3(nb), dim3(NTG), 0, (hipStream_t)stream, a);
     int rc = zs_check_launch("zs_gru_bwd.gate");
     if (rc) return rc;
-    if (s < T - 1) {
+    if (s < T - 1 && H % 32 == 0) {
+      RowGemmArgs a;
+      memset(&a, 0, sizeof(a));
+      const int64_t off0 = (int64_t)(T - 1 - s) * p->ldgh;
+      const int64_t off1 = (int64_t)s * p->ldgh + 3 * H;
+      a.A = dghb + off0 * es; a.a_row_stride = (int64_t)T * p->ldgh; a.a_gstride = off1 - off0;
+      a.W = p->whh_t; a.ldw = p->ldw; a.w_gstride = p->w_gstride;
+      a.M = B; a.N = H; a.K = 3 * H;
+      a.out = dhg; a.out_gstride = (int64_t)B * H;
+      dim3 grid(H / 32, (B + 63) / 64, 2);
+      if (p->dtype == ZS_F32) hipLaunchKernelGGL((rowblock_gemm_kernel<float, 2, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((rowblock_gemm_kernel<bf16_t, 2, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      rc = zs_check_launch("zs_gru_bwd.step");
+      if (rc) return rc;
+    } else if (s < T - 1) {
       ZsGemmConv g;
       memset(&g, 0, sizeof(g));
       g.dtype = p->dtype;

@@ -232,6 +232,13 @@ class GruLayer(object):
         self.hh_ldw_t, self.hh_npad_t = rup(rup(3 * H, 32), 64), rup(H, 128)
         self.whh_t = torch.zeros(2 * self.hh_npad_t * self.hh_ldw_t + SLACK, dtype=tdt, device=dev)
         self.bhh = torch.zeros(2 * 3 * H, dtype=torch.float32, device=dev)
+        # fast recurrent path (zs_amd.h: zs_gru_fwd): rows of W_hh gate-interleaved per 32 hidden units
+        self.fast = (H % 32 == 0)
+        self.perm = None
+        if self.fast:
+            n = torch.arange(3 * H)
+            hc, rem = n // 96, n % 96
+            self.perm = ((rem // 32) * H + hc * 32 + (rem % 32)).to(torch.int32).to(dev)
 
     def pack(self):
         c, H, Cin = self.ctx, self.H, self.Cin
@@ -243,8 +250,8 @@ class GruLayer(object):
                    ldw=self.ih_ldw_d, n_rows=self.ih_npad_d, n_cols=3 * H, col_offset=3 * H * d, **com)
             com = dict(dtype=c.dt, so=H, si=1, sj=0, Cout=3 * H, Cin=H, taps=1, co_split2=0, W=L.ptr(self.w_hh[d]))
             L.call('zs_pack_weight', 'ZsPackWeight', c.stream, transpose=0, inner_pad=rup(H, 32),
-                   dst=L.ptr(self.whh_f, d * self.hh_npad * self.hh_ldw), ldw=self.hh_ldw, n_rows=self.hh_npad,
-                   n_cols=self.hh_ldw, **com)
+                   dst=L.ptr(self.whh_f, d * self.hh_npad * self.hh_ldw), ldw=self.hh_ldw,
+                   n_rows=(3 * H if self.fast else self.hh_npad), n_cols=self.hh_ldw, row_perm=L.ptr(self.perm), **com)
             L.call('zs_pack_weight', 'ZsPackWeight', c.stream, transpose=1, inner_pad=rup(3 * H, 32),
                    dst=L.ptr(self.whh_t, d * self.hh_npad_t * self.hh_ldw_t), ldw=self.hh_ldw_t, n_rows=self.hh_npad_t,
                    n_cols=self.hh_ldw_t, **com)
@@ -267,7 +274,8 @@ class GruLayer(object):
         L.call('zs_gru_fwd', 'ZsGruFwd', c.stream, dtype=c.dt, B=X.B, T=X.T, H=H, gi=gi.ptr(), ldgi=gi.ld,
                whh=L.ptr(self.whh_f), ldw=self.hh_ldw, n_pad=self.hh_npad, w_gstride=self.hh_npad * self.hh_ldw,
                bhh=L.ptr(self.bhh), bhh_gstride=3 * H, out=out.ptr(), ldo=out.ld, out_col=out_col,
-               gates=L.ptr(gates) if gates is not None else None, work=L.ptr(work), work_bytes=work.numel() * 4)
+               gates=L.ptr(gates) if gates is not None else None, work=L.ptr(work), work_bytes=work.numel() * 4,
+               whh_interleaved=int(self.fast))
 
     def bwd(self, dout, dout_col, out, out_col, gates, X, dgi, dgh, dX, add_src=None):
         """BPTT + parameter gradients + input gradient dX (= dgi W_ih, + add_src)."""
