@@ -100,9 +100,9 @@ __global__ void gru_gate_bwd_kernel(const GateBwdArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // Small-M product for the recurrence: out[M, N] = A[M, K] * W[N, K]^T with M = batch (a few hundred rows).
-// One wave owns 16 rows x (16*NT16) columns; operands are loaded as MFMA fragments straight from global
-// memory (they are L2/MALL resident: h_{t-1} and W_hh are re-read every step), 16 B per lane per fragment,
-// no LDS and no barrier, so the waves of a step never wait on each other.  bf16: v_mfma_f32_16x16x32_bf16;
+// One workgroup owns 16 rows x (16*NT16) columns and its 4 waves split K (one LDS reduce at the end); operands
+// are loaded as MFMA fragments straight from global memory (L2/MALL resident: h_{t-1} and W_hh are re-read
+// every step), 16 B per lane per fragment, so the serial chain of a step is K/4 deep and 2 workgroups/CU run.  bf16: v_mfma_f32_16x16x32_bf16;
 // fp32: four v_mfma_f32_16x16x4_f32 per 16-byte fragment (lane q supplies k = 4q+s in step s on both sides).
 // GRU = true fuses the forward gate math: W rows are packed [r(32) | z(32) | n(32)] per 32 hidden units, so
 // a lane's accumulators (col = lane&15) of tiles {0,1}/{2,3}/{4,5} are r/z/n of the SAME (row, unit).
@@ -136,26 +136,52 @@ template <> struct Frag16<float> {
 
 template <typename T, int NT16, bool GRU>
 __global__ __launch_bounds__(256) void rowblock_gemm_kernel(const RowGemmArgs a) {
+  // workgroup = one 16-row x (16*NT16)-column tile; its 4 waves split K and reduce through LDS
   constexpr int KSTEP = Frag16<T>::KSTEP;
   constexpr int EPL = 16 / (int)sizeof(T);            // elements per lane per fragment
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float part[4][NT16][4][64];               // [wave][tile][reg][lane]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, r = lane & 15;
   const int g = blockIdx.z;
-  const int m0 = (blockIdx.y * 4 + wave) * 16;
-  if (m0 >= a.M) return;                               // whole wave out of range (no barriers in this kernel)
+  const int m0 = blockIdx.y * 16;
   const int n0 = blockIdx.x * (16 * NT16);
   const int row = m0 + r;
   const bool rvalid = row < a.M;
-  const T* Arow = (const T*)a.A + (int64_t)g * a.a_gstride + (int64_t)(rvalid ? row : m0) * a.a_row_stride + q * EPL;
-  const T* Wrow = (const T*)a.W + (int64_t)g * a.w_gstride + (int64_t)(n0 + r) * a.ldw + q * EPL;
+  const bool skip = GRU && (a.gate.step == 0);         // h_{-1} = 0
+
+  // ---- GRU epilogue operands: issue their loads first so they fly under the K loop ----
+  // thread -> 2 (row, unit) pairs: unit u = tid & 31, rows e_row and e_row + 8
+  const int eu = tid & 31, e_row = tid >> 5;
+  float e_gi[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, e_hp[2] = {0.f, 0.f}, e_b[3] = {0.f, 0.f, 0.f};
+  int e_t = 0;
+  if constexpr (GRU) {
+    const GateFwdArgs& ga = a.gate;
+    const int d = g, H = ga.H, j = blockIdx.x * 32 + eu;
+    e_t = d == 0 ? ga.step : ga.T - 1 - ga.step;
+    const float* bh = ga.bhh + (int64_t)d * ga.bhh_gstride;
+    e_b[0] = bh[j]; e_b[1] = bh[H + j]; e_b[2] = bh[2 * H + j];
+#pragma unroll
+    for (int pz = 0; pz < 2; ++pz) {
+      const int b = m0 + e_row + 8 * pz;
+      if (b < a.M) {
+        const T* gi = (const T*)ga.gi + ((int64_t)b * ga.T + e_t) * ga.ldgi + (int64_t)d * 3 * H;
+        e_gi[pz][0] = Elem<T>::ld(gi + j); e_gi[pz][1] = Elem<T>::ld(gi + H + j); e_gi[pz][2] = Elem<T>::ld(gi + 2 * H + j);
+        if (!skip) e_hp[pz] = ga.hstate[((int64_t)d * ga.B + b) * H + j];
+      }
+    }
+  }
+
   f32x4_t acc[NT16];
 #pragma unroll
   for (int c = 0; c < NT16; ++c) acc[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const bool skip = GRU && (a.gate.step == 0);         // h_{-1} = 0
   if (!skip) {
+    const T* Arow = (const T*)a.A + (int64_t)g * a.a_gstride + (int64_t)(rvalid ? row : m0) * a.a_row_stride + q * EPL;
+    const T* Wrow = (const T*)a.W + (int64_t)g * a.w_gstride + (int64_t)(n0 + r) * a.ldw + q * EPL;
     const int nks = a.K / KSTEP;
-    int ks = 0;
-    for (; ks + 4 <= nks; ks += 4) {                   // 4 k-steps of fragments in flight before the first MFMA
+    const int per = (nks + 3) >> 2;
+    int ks = wave * per;
+    const int kend = min(nks, ks + per);
+    for (; ks + 4 <= kend; ks += 4) {                  // 4 k-steps of fragments in flight before the first MFMA
       uint4 fa[4], fb[4][NT16];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -170,7 +196,7 @@ __global__ __launch_bounds__(256) void rowblock_gemm_kernel(const RowGemmArgs a)
         for (int c = 0; c < NT16; ++c) Frag16<T>::mma(fa[u], fb[u][c], acc[c]);
       }
     }
-    for (; ks < nks; ++ks) {
+    for (; ks < kend; ++ks) {
       uint4 fa = *reinterpret_cast<const uint4*>(Arow + ks * KSTEP);
       if (!rvalid) fa = make_uint4(0, 0, 0, 0);
 #pragma unroll
@@ -180,41 +206,44 @@ __global__ __launch_bounds__(256) void rowblock_gemm_kernel(const RowGemmArgs a)
       }
     }
   }
+#pragma unroll
+  for (int c = 0; c < NT16; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) part[wave][c][i][lane] = acc[c][i];
+  __syncthreads();
+  // element (row rr, col cc) of tile c lives at reg i = rr & 3 of lane (rr >> 2) * 16 + cc
+  auto total = [&](int c, int rr, int cc) -> float {
+    const int l = (rr >> 2) * 16 + cc, i = rr & 3;
+    return (part[0][c][i][l] + part[1][c][i][l]) + (part[2][c][i][l] + part[3][c][i][l]);
+  };
   if constexpr (!GRU) {
     float* out = a.out + (int64_t)g * a.out_gstride;
-#pragma unroll
-    for (int c = 0; c < NT16; ++c)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0 + 4 * q + i;
-        if (m < a.M) out[(int64_t)m * a.N + n0 + 16 * c + r] = acc[c][i];
-      }
+    constexpr int NC = 16 * NT16;
+    for (int e = tid; e < 16 * NC; e += 256) {          // coalesced along the columns
+      const int rr = e / NC, col = e - rr * NC;
+      const int m = m0 + rr;
+      if (m < a.M) out[(int64_t)m * a.N + n0 + col] = total(col >> 4, rr, col & 15);
+    }
   } else {
     const GateFwdArgs& ga = a.gate;
-    const int d = g, H = ga.H;
-    const int t = d == 0 ? ga.step : ga.T - 1 - ga.step;
-    const float* bh = ga.bhh + (int64_t)d * ga.bhh_gstride;
+    const int d = g, H = ga.H, j = blockIdx.x * 32 + eu;
+    const int hh = eu >> 4, cc = eu & 15;
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int j = blockIdx.x * 32 + hh * 16 + r;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int b = m0 + 4 * q + i;
-        if (b >= a.M) continue;
-        const T* gi = (const T*)ga.gi + ((int64_t)b * ga.T + t) * ga.ldgi + (int64_t)d * 3 * H;
-        const int64_t si = ((int64_t)d * ga.B + b) * H + j;
-        const float hp = skip ? 0.f : ga.hstate[si];
-        const float rg = 1.f / (1.f + expf(-(Elem<T>::ld(gi + j) + (acc[hh][i] + bh[j]))));
-        const float zg = 1.f / (1.f + expf(-(Elem<T>::ld(gi + H + j) + (acc[2 + hh][i] + bh[H + j]))));
-        const float hn = acc[4 + hh][i] + bh[2 * H + j];
-        const float ng = tanhf(Elem<T>::ld(gi + 2 * H + j) + rg * hn);
-        const float h = (1.f - zg) * ng + zg * hp;
-        ga.hstate[si] = h;
-        Elem<T>::st((T*)ga.out + ((int64_t)b * ga.T + t) * ga.ldo + ga.out_col + d * H + j, h);
-        if (ga.gates) {
-          T* gs = (T*)ga.gates + (((int64_t)b * ga.T + t) * 2 + d) * 4 * H;
-          Elem<T>::st(gs + j, rg); Elem<T>::st(gs + H + j, zg); Elem<T>::st(gs + 2 * H + j, ng); Elem<T>::st(gs + 3 * H + j, hn);
-        }
+    for (int pz = 0; pz < 2; ++pz) {
+      const int rr = e_row + 8 * pz;
+      const int b = m0 + rr;
+      if (b >= a.M) continue;
+      const float ghr = total(hh, rr, cc), ghz = total(2 + hh, rr, cc), ghn = total(4 + hh, rr, cc);
+      const float rg = 1.f / (1.f + expf(-(e_gi[pz][0] + (ghr + e_b[0]))));
+      const float zg = 1.f / (1.f + expf(-(e_gi[pz][1] + (ghz + e_b[1]))));
+      const float hn = ghn + e_b[2];
+      const float ng = tanhf(e_gi[pz][2] + rg * hn);
+      const float h = (1.f - zg) * ng + zg * e_hp[pz];
+      ga.hstate[((int64_t)d * ga.B + b) * H + j] = h;
+      Elem<T>::st((T*)ga.out + ((int64_t)b * ga.T + e_t) * ga.ldo + ga.out_col + d * H + j, h);
+      if (ga.gates) {
+        T* gs = (T*)ga.gates + (((int64_t)b * ga.T + e_t) * 2 + d) * 4 * H;
+        Elem<T>::st(gs + j, rg); Elem<T>::st(gs + H + j, zg); Elem<T>::st(gs + 2 * H + j, ng); Elem<T>::st(gs + 3 * H + j, hn);
       }
     }
   }
@@ -258,7 +287,7 @@ extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
       GateFwdArgs& g = a.gate;
       g.gi = p->gi; g.ldgi = p->ldgi; g.gh = nullptr; g.bhh = p->bhh; g.bhh_gstride = p->bhh_gstride; g.hstate = hstate;
       g.out = p->out; g.ldo = p->ldo; g.out_col = p->out_col; g.gates = p->gates; g.B = B; g.T = T; g.H = H; g.step = s;
-      dim3 grid(H / 32, (B + 63) / 64, 2);
+      dim3 grid(H / 32, (B + 15) / 16, 2);
       if (p->dtype == ZS_F32) hipLaunchKernelGGL((rowblock_gemm_kernel<float, 6, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
       else hipLaunchKernelGGL((rowblock_gemm_kernel<bf16_t, 6, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
       int rc = zs_check_launch("zs_gru_fwd.step");
@@ -325,7 +354,7 @@ extern "C" int zs_gru_bwd(const ZsGruBwd* p, void* stream) {
       a.W = p->whh_t; a.ldw = p->ldw; a.w_gstride = p->w_gstride;
       a.M = B; a.N = H; a.K = 3 * H;
       a.out = dhg; a.out_gstride = (int64_t)B * H;
-      dim3 grid(H / 32, (B + 63) / 64, 2);
+      dim3 grid(H / 32, (B + 15) / 16, 2);
       if (p->dtype == ZS_F32) hipLaunchKernelGGL((rowblock_gemm_kernel<float, 2, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
       else hipLaunchKernelGGL((rowblock_gemm_kernel<bf16_t, 2, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
       rc = zs_check_launch("zs_gru_bwd.step");
