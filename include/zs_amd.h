@@ -58,8 +58,10 @@ typedef struct {
   const void* A; int64_t lda; int64_t a_batch_stride;
   int32_t B, T_in, T_out;
   int32_t taps, stride, pad_left, pad_mode, gather;
-  int32_t cin_pad;                 /* K per tap, multiple of 32 */
-  const void* W; int64_t ldw;      /* packed [n_pad][ldw], ldw = roundup(taps*cin_pad, 64), zero padded */
+  int32_t cin_pad;                 /* K per tap: a whole number of 128-byte chunks (multiple of 64 bf16 / 32 fp32).
+                                      A rows are read up to cin_pad columns: bytes past C must be finite (zeros or the
+                                      next row), the matching W columns are zero */
+  const void* W; int64_t ldw;      /* packed [n_pad][ldw], ldw >= taps*cin_pad, zero padded */
   int32_t N, n_pad;                /* valid columns; packed rows (multiple of 128) */
   const float* bias;
   const float* pre_vec; int64_t pre_vec_ld; const int64_t* vec_idx;

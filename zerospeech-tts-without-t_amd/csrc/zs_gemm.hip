@@ -25,6 +25,8 @@ constexpr int ROWB = 128;    // bytes of K per LDS row
 constexpr int PITCH = 144;   // LDS row pitch (bytes)
 constexpr int TILE_BYTES = BM * PITCH;
 
+__device__ const uint4 zs_zero_line[8] = {};   // 128 B of zeros: the source of every "zero row" chunk
+
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -78,64 +80,72 @@ __global__ __launch_bounds__(NT, 2) void gemm_conv_kernel(const ZsGemmConv p) {
   const int M = p.B * p.T_out;
   const int ntn = (p.N + BN - 1) / BN;
   const int ntm = (M + BM - 1) / BM;
+  // tile order: XCD-contiguous ids, then groups of GM m-tiles swept n-major, so the ~64 tiles resident on one
+  // XCD form an (8 x up-to-8) block and share BOTH their A and W panels through that XCD's L2
   const int wg = xcd_remap(blockIdx.x, ntm * ntn);
-  const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
+  constexpr int GM = 8;
+  const int per_group = GM * ntn;
+  const int grp = wg / per_group;
+  const int gm = min(GM, ntm - grp * GM);           // rows in this (possibly last, shorter) group
+  const int in_g = wg - grp * per_group;
+  const int m0 = (grp * GM + in_g % gm) * BM, n0 = (in_g / gm) * BN;
 
   // ---- loader state: 4 rows x one 16-B segment per thread, for A and for W ----
+  // cin_pad is a whole number of 128-byte chunks, so a chunk never straddles two taps and the tap change is
+  // wave-uniform: per chunk the loader only bumps running pointers; rows that contribute zeros (padding,
+  // rows beyond M, invalid transposed-conv positions) point at a resident zero line and do not advance.
   const int seg = tid & 7, r0 = tid >> 3;
   int rb[4], rt[4];            // sample / position of the 4 A rows (rb<0: row beyond M)
-  int64_t aoff[4];             // element offset of the current tap's source row (-1: zero row)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int m = m0 + r0 + 32 * i;
     if (m < M) { rb[i] = m / p.T_out; rt[i] = m - rb[i] * p.T_out; } else { rb[i] = -1; rt[i] = 0; }
   }
-  const int ktaps = p.taps, cin_pad = p.cin_pad;
-  int tap = (seg * EPS) / cin_pad;
-  int ci = seg * EPS - tap * cin_pad;
-  auto set_tap = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      bool ok = false; int s = 0;
-      if (rb[i] >= 0 && tap < ktaps) s = conv_src_row(p.gather, p.pad_mode, p.stride, p.pad_left, p.T_in, rt[i], tap, ok);
-      aoff[i] = ok ? ((int64_t)rb[i] * p.a_batch_stride + (int64_t)s * p.lda) : (int64_t)-1;
+  const int chunks_per_tap = p.cin_pad / KC;
+  const T* zline = reinterpret_cast<const T*>(zs_zero_line) + seg * EPS;
+  const T *pa0, *pa1, *pa2, *pa3;
+  int inc0, inc1, inc2, inc3;                 // per-chunk advance (0 for zero rows)
+#define ZS_SET_TAP(i, ptr, inc)                                                                         \
+  {                                                                                                     \
+    bool ok = false; int srow = 0;                                                                      \
+    if (rb[i] >= 0) srow = conv_src_row(p.gather, p.pad_mode, p.stride, p.pad_left, p.T_in, rt[i], tap, ok); \
+    ptr = ok ? (A + (int64_t)rb[i] * p.a_batch_stride + (int64_t)srow * p.lda + seg * EPS) : zline;       \
+    inc = ok ? KC : 0;                                                                                  \
+  }
+  const T* pw0 = W + (int64_t)(n0 + r0) * p.ldw + seg * EPS;
+  const int64_t wstep = (int64_t)32 * p.ldw;
+
+  const int nk = p.taps * chunks_per_tap;
+  // Two register stages of individually named registers, filled/drained by macros: hipcc demoted both arrays and
+  // structs captured by (or passed by reference to) the loader lambdas to scratch memory.  Loads run two
+  // chunks ahead of the MFMAs.
+  uint4 Pa0, Pa1, Pa2, Pa3, Pb0, Pb1, Pb2, Pb3, Qa0, Qa1, Qa2, Qa3, Qb0, Qb1, Qb2, Qb3;
+  int tap = 0, cit = 0;                       // wave-uniform K cursor: tap and chunk within tap
+  { ZS_SET_TAP(0, pa0, inc0) ZS_SET_TAP(1, pa1, inc1) ZS_SET_TAP(2, pa2, inc2) ZS_SET_TAP(3, pa3, inc3) }
+  auto advance = [&]() {
+    pw0 += KC;
+    if (++cit == chunks_per_tap) {            // uniform branch: next tap -> new source rows
+      cit = 0; ++tap;
+      if (tap < p.taps) { ZS_SET_TAP(0, pa0, inc0) ZS_SET_TAP(1, pa1, inc1) ZS_SET_TAP(2, pa2, inc2) ZS_SET_TAP(3, pa3, inc3) }
+    } else {
+      pa0 += inc0; pa1 += inc1; pa2 += inc2; pa3 += inc3;
     }
   };
-  set_tap();
-  const T* wrow[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) wrow[i] = W + (int64_t)(n0 + r0 + 32 * i) * p.ldw + seg * EPS;
-
-  const int nk = (int)(p.ldw / KC);
-  // staging registers are individually named (arrays captured by the loader lambdas were demoted to
-  // scratch memory by hipcc: 8 scratch accesses per K chunk)
-  uint4 va0, va1, va2, va3, vb0, vb1, vb2, vb3;
-#define ZS_LOAD_A(i, dst)                                                                             \
-  {                                                                                                   \
-    const bool ok = aoff[i] >= 0; /* branch-free: load row 0 for a zero row, then select */          \
-    const uint4 v = *reinterpret_cast<const uint4*>(A + (ok ? aoff[i] : (int64_t)0) + ci);            \
-    dst.x = ok ? v.x : 0u; dst.y = ok ? v.y : 0u; dst.z = ok ? v.z : 0u; dst.w = ok ? v.w : 0u;       \
+#define ZS_GLOAD(S)                                                                                      \
+  S##a0 = *reinterpret_cast<const uint4*>(pa0); S##a1 = *reinterpret_cast<const uint4*>(pa1);            \
+  S##a2 = *reinterpret_cast<const uint4*>(pa2); S##a3 = *reinterpret_cast<const uint4*>(pa3);            \
+  S##b0 = *reinterpret_cast<const uint4*>(pw0); S##b1 = *reinterpret_cast<const uint4*>(pw0 + wstep);    \
+  S##b2 = *reinterpret_cast<const uint4*>(pw0 + 2 * wstep); S##b3 = *reinterpret_cast<const uint4*>(pw0 + 3 * wstep); \
+  advance();
+#define ZS_SWRITE(S, buf)                                                                                \
+  {                                                                                                      \
+    unsigned char* pa_ = sA + (buf) * TILE_BYTES + r0 * PITCH + seg * 16;                                \
+    unsigned char* pb_ = sB + (buf) * TILE_BYTES + r0 * PITCH + seg * 16;                                \
+    *reinterpret_cast<uint4*>(pa_) = S##a0; *reinterpret_cast<uint4*>(pa_ + 32 * PITCH) = S##a1;          \
+    *reinterpret_cast<uint4*>(pa_ + 64 * PITCH) = S##a2; *reinterpret_cast<uint4*>(pa_ + 96 * PITCH) = S##a3; \
+    *reinterpret_cast<uint4*>(pb_) = S##b0; *reinterpret_cast<uint4*>(pb_ + 32 * PITCH) = S##b1;          \
+    *reinterpret_cast<uint4*>(pb_ + 64 * PITCH) = S##b2; *reinterpret_cast<uint4*>(pb_ + 96 * PITCH) = S##b3; \
   }
-  auto gload = [&](int kt) {
-    ZS_LOAD_A(0, va0) ZS_LOAD_A(1, va1) ZS_LOAD_A(2, va2) ZS_LOAD_A(3, va3)
-    vb0 = *reinterpret_cast<const uint4*>(wrow[0] + (int64_t)kt * KC);
-    vb1 = *reinterpret_cast<const uint4*>(wrow[1] + (int64_t)kt * KC);
-    vb2 = *reinterpret_cast<const uint4*>(wrow[2] + (int64_t)kt * KC);
-    vb3 = *reinterpret_cast<const uint4*>(wrow[3] + (int64_t)kt * KC);
-    ci += KC;                                  // advance this thread's K cursor to the next chunk
-    bool moved = false;
-    while (ci >= cin_pad) { ci -= cin_pad; ++tap; moved = true; }
-    if (moved) set_tap();
-  };
-#undef ZS_LOAD_A
-  auto swrite = [&](int buf) {
-    unsigned char* pa = sA + buf * TILE_BYTES + r0 * PITCH + seg * 16;
-    unsigned char* pb = sB + buf * TILE_BYTES + r0 * PITCH + seg * 16;
-    *reinterpret_cast<uint4*>(pa) = va0; *reinterpret_cast<uint4*>(pa + 32 * PITCH) = va1;
-    *reinterpret_cast<uint4*>(pa + 64 * PITCH) = va2; *reinterpret_cast<uint4*>(pa + 96 * PITCH) = va3;
-    *reinterpret_cast<uint4*>(pb) = vb0; *reinterpret_cast<uint4*>(pb + 32 * PITCH) = vb1;
-    *reinterpret_cast<uint4*>(pb + 64 * PITCH) = vb2; *reinterpret_cast<uint4*>(pb + 96 * PITCH) = vb3;
-  };
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -145,13 +155,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_conv_kernel(const ZsGemmConv p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  gload(0);
-  swrite(0);
-  __syncthreads();
   const int frow = lane & 31, fh = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
+  auto compute = [&](int buf) {
     const unsigned char* a_base = sA + buf * TILE_BYTES + (wm * 64 + frow) * PITCH + fh * 16;
     const unsigned char* b_base = sB + buf * TILE_BYTES + (wn * 64 + frow) * PITCH + fh * 16;
 #pragma unroll
@@ -166,9 +171,28 @@ __global__ __launch_bounds__(NT, 2) void gemm_conv_kernel(const ZsGemmConv p) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) Mma<T>::run(fa[mi], fb[ni], acc[mi][ni]);
     }
-    if (kt + 1 < nk) swrite(buf ^ 1);
+  };
+
+  ZS_GLOAD(P)
+  if (nk > 1) { ZS_GLOAD(Q) }
+  ZS_SWRITE(P, 0)
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    // even chunk kt lives in LDS buffer 0; Q holds chunk kt+1 (in flight); P is free
+    if (kt + 2 < nk) { ZS_GLOAD(P) }
+    compute(0);
+    if (kt + 1 < nk) ZS_SWRITE(Q, 1)
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    // odd chunk kt+1 lives in LDS buffer 1; P holds chunk kt+2 (in flight); Q is free
+    if (kt + 3 < nk) { ZS_GLOAD(Q) }
+    compute(1);
+    if (kt + 2 < nk) ZS_SWRITE(P, 0)
     __syncthreads();
   }
+#undef ZS_GLOAD
+#undef ZS_SWRITE
+#undef ZS_SET_TAP
 
   // ---- epilogue ----
   const bool need_b = (p.pre_vec != nullptr) || (p.vec2 != nullptr);
@@ -459,9 +483,9 @@ extern "C" int zs_gemm_conv(const ZsGemmConv* p, void* stream) {
   const int es = p->dtype == ZS_F32 ? 4 : 2;
   const int kc = 128 / es;
   ZS_REQUIRE(p->B > 0 && p->T_in > 0 && p->T_out > 0 && p->N > 0 && p->taps > 0 && p->stride > 0, "zs_gemm_conv: bad sizes");
-  ZS_REQUIRE(p->cin_pad > 0 && p->cin_pad % 32 == 0, "zs_gemm_conv: cin_pad %d must be a multiple of 32", p->cin_pad);
-  ZS_REQUIRE(p->ldw % kc == 0 && p->ldw >= (int64_t)p->taps * p->cin_pad, "zs_gemm_conv: ldw %lld not a padded multiple of %d",
-             (long long)p->ldw, kc);
+  ZS_REQUIRE(p->cin_pad > 0 && p->cin_pad % kc == 0, "zs_gemm_conv: cin_pad %d must be a multiple of %d (one 128-byte chunk)", p->cin_pad, kc);
+  ZS_REQUIRE(p->ldw >= (int64_t)p->taps * p->cin_pad && (p->ldw * es) % 16 == 0, "zs_gemm_conv: ldw %lld < taps*cin_pad",
+             (long long)p->ldw);
   ZS_REQUIRE(p->n_pad % 128 == 0 && p->n_pad >= p->N, "zs_gemm_conv: n_pad %d must be a multiple of 128 >= N %d", p->n_pad, p->N);
   ZS_REQUIRE(aligned16(p->A) && aligned16(p->W) && (p->lda * es) % 16 == 0 && (p->a_batch_stride * es) % 16 == 0 &&
                  (p->a_gstride * es) % 16 == 0 && (p->w_gstride * es) % 16 == 0,

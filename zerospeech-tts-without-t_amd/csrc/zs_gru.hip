@@ -268,6 +268,7 @@ extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
   ZS_REQUIRE(p->B > 0 && p->T > 0 && p->H > 0 && p->H % 8 == 0, "zs_gru_fwd: sizes (H %% 8 == 0 required, H=%d)", p->H);
   ZS_REQUIRE(p->work_bytes >= zs_gru_work_bytes(p->B, p->H), "zs_gru_fwd: work buffer too small");
   const int es = p->dtype == ZS_F32 ? 4 : 2;
+  const int kc = 128 / es;
   ZS_REQUIRE((p->out_col * es) % 16 == 0, "zs_gru_fwd: out_col alignment");
   const int B = p->B, T = p->T, H = p->H;
   float* gh = p->work;
@@ -305,7 +306,7 @@ extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
       g.A = outb + off0 * es; g.lda = p->ldo; g.a_batch_stride = (int64_t)T * p->ldo;
       g.a_gstride = off1 - off0;
       g.B = B; g.T_in = 1; g.T_out = 1; g.taps = 1; g.stride = 1; g.pad_left = 0; g.pad_mode = ZS_PAD_ZERO; g.gather = 0;
-      g.cin_pad = ((H + 31) / 32) * 32;
+      g.cin_pad = ((H + kc - 1) / kc) * kc;
       g.W = p->whh; g.ldw = p->ldw; g.w_gstride = p->w_gstride; g.N = 3 * H; g.n_pad = p->n_pad;
       g.act = ZS_ACT_NONE;
       g.out = gh; g.ldc = 3 * H; g.out_f32 = 1; g.out_cols = 3 * H; g.store_mode = ZS_STORE_ROWS; g.out_gstride = (int64_t)B * 3 * H;
@@ -331,6 +332,7 @@ extern "C" int zs_gru_bwd(const ZsGruBwd* p, void* stream) {
   ZS_REQUIRE(p->B > 0 && p->T > 0 && p->H > 0 && p->H % 8 == 0, "zs_gru_bwd: sizes");
   ZS_REQUIRE(p->work_bytes >= zs_gru_work_bytes(p->B, p->H), "zs_gru_bwd: work buffer too small");
   const int es = p->dtype == ZS_F32 ? 4 : 2;
+  const int kc = 128 / es;
   const int B = p->B, T = p->T, H = p->H;
   float* dhd = p->work + (size_t)2 * B * 3 * H;
   float* dhg = dhd + (size_t)2 * B * H;
@@ -367,7 +369,7 @@ extern "C" int zs_gru_bwd(const ZsGruBwd* p, void* stream) {
       const int64_t off1 = (int64_t)s * p->ldgh + 3 * H;              // dir 1 row t = s,     columns [3H,6H)
       g.A = dghb + off0 * es; g.lda = p->ldgh; g.a_batch_stride = (int64_t)T * p->ldgh; g.a_gstride = off1 - off0;
       g.B = B; g.T_in = 1; g.T_out = 1; g.taps = 1; g.stride = 1; g.pad_left = 0; g.pad_mode = ZS_PAD_ZERO; g.gather = 0;
-      g.cin_pad = ((3 * H + 31) / 32) * 32;
+      g.cin_pad = ((3 * H + kc - 1) / kc) * kc;
       g.W = p->whh_t; g.ldw = p->ldw; g.w_gstride = p->w_gstride; g.N = H; g.n_pad = p->n_pad;
       g.act = ZS_ACT_NONE;
       g.out = dhg; g.ldc = H; g.out_f32 = 1; g.out_cols = H; g.store_mode = ZS_STORE_ROWS; g.out_gstride = (int64_t)B * H;

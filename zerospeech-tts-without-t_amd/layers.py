@@ -57,6 +57,7 @@ class Ctx(object):
         self.dtype_name = dtype
         self.dt, self.tdt = DTYPES[dtype]
         self.es = 4 if dtype == 'fp32' else 2
+        self.kc = 128 // self.es
         self._bufs = {}
         self._ws = None
 
@@ -103,9 +104,10 @@ class ConvLayer(object):
         self.pad_l = self.k // 2
         self.pad_r = self.k - 1 - self.k // 2
         self.so, self.si, self.sj = (self.Cin * self.k, self.k, 1) if weight.dim() == 3 else (self.Cin, 1, 0)
-        self.cin_pad, self.cout_pad = rup(self.Cin, 32), rup(self.Cout, 32)
-        self.ldw, self.n_pad = rup(self.k * self.cin_pad, 64), rup(self.Cout, 128)
-        self.ldw_d, self.n_pad_d = rup(self.k * self.cout_pad, 64), rup(self.Cin, 128)
+        kc = ctx.kc                                       # elements per 128-byte K chunk
+        self.cin_pad, self.cout_pad = rup(self.Cin, kc), rup(self.Cout, kc)
+        self.ldw, self.n_pad = self.k * self.cin_pad, rup(self.Cout, 128)
+        self.ldw_d, self.n_pad_d = self.k * self.cout_pad, rup(self.Cin, 128)
         dev, tdt = ctx.device, ctx.tdt
         self.wf = torch.zeros(self.n_pad * self.ldw + SLACK, dtype=tdt, device=dev)
         self.wd = torch.zeros(self.n_pad_d * self.ldw_d + SLACK, dtype=tdt, device=dev)
@@ -137,7 +139,6 @@ class ConvLayer(object):
         """A: Act [B,T_in,Cin] -> out Act [B,T_out,Cout] (or pixel-shuffled).  Returns T_out."""
         c = self.ctx
         T_out = self.t_out(A.T)
-        assert A.ld >= self.cin_pad or A.cols >= self.cin_pad, (self.name, A.ld, self.cin_pad)
         kw = dict(dtype=c.dt, A=A.ptr(), lda=A.ld, a_batch_stride=A.T * A.ld, B=A.B, T_in=A.T, T_out=T_out, taps=self.k,
                   stride=self.stride, pad_left=self.pad_l, pad_mode=self.pad_mode, gather=0, cin_pad=self.cin_pad,
                   W=L.ptr(self.wf), ldw=self.ldw, N=self.Cout, n_pad=self.n_pad, bias=self.bias_ptr(), act=act, slope=slope,
@@ -163,7 +164,7 @@ class ConvLayer(object):
         kw = dict(dtype=c.dt, A=dY.ptr(), lda=dY.ld, a_batch_stride=dY.T * dY.ld, B=dY.B, T_in=dY.T, T_out=Tp, taps=self.k,
                   stride=self.stride, pad_left=0, pad_mode=L.ZS_PAD_ZERO, gather=1, cin_pad=self.cout_pad,
                   W=L.ptr(self.wd), ldw=self.ldw_d, N=self.Cin, n_pad=self.n_pad_d, act=L.ZS_ACT_NONE, slope=slope,
-                  out=out.ptr(), ldc=out.ld, out_cols=min(out.cols, self.cin_pad), store_mode=L.ZS_STORE_ROWS, groups=1)
+                  out=out.ptr(), ldc=out.ld, out_cols=min(out.cols, rup(self.Cin, 32)), store_mode=L.ZS_STORE_ROWS, groups=1)
         if dact_src is not None:
             kw.update(dact_src=dact_src.ptr(), dact_ld=dact_src.ld)
         if add_src is not None:
@@ -218,18 +219,19 @@ class GruLayer(object):
             raise ValueError('GRU hidden size must be a multiple of 8 (got %d)' % H)
         dev, tdt = ctx.device, ctx.tdt
         self.G6 = 6 * H
-        self.g6_pad = rup(6 * H, 32)
+        self.g6_pad = rup(6 * H, ctx.kc)
         # input projection, both directions stacked on the output axis: [6H][Cin]
-        self.cin_pad = rup(Cin, 32)
-        self.ih_ldw, self.ih_npad = rup(self.cin_pad, 64), rup(6 * H, 128)
+        kc = ctx.kc
+        self.cin_pad = rup(Cin, kc)
+        self.ih_ldw, self.ih_npad = self.cin_pad, rup(6 * H, 128)
         self.wih_f = torch.zeros(self.ih_npad * self.ih_ldw + SLACK, dtype=tdt, device=dev)
-        self.ih_ldw_d, self.ih_npad_d = rup(self.g6_pad, 64), rup(Cin, 128)
+        self.ih_ldw_d, self.ih_npad_d = self.g6_pad, rup(Cin, 128)
         self.wih_d = torch.zeros(self.ih_npad_d * self.ih_ldw_d + SLACK, dtype=tdt, device=dev)
         self.bih = torch.zeros(6 * H, dtype=torch.float32, device=dev)
         # recurrent: forward [2][n_pad(3H)][ldw(H)], transposed [2][n_pad(H)][ldw(3H)]
-        self.hh_ldw, self.hh_npad = rup(rup(H, 32), 64), rup(3 * H, 128)
+        self.hh_ldw, self.hh_npad = rup(H, kc), rup(3 * H, 128)
         self.whh_f = torch.zeros(2 * self.hh_npad * self.hh_ldw + SLACK, dtype=tdt, device=dev)
-        self.hh_ldw_t, self.hh_npad_t = rup(rup(3 * H, 32), 64), rup(H, 128)
+        self.hh_ldw_t, self.hh_npad_t = rup(3 * H, kc), rup(H, 128)
         self.whh_t = torch.zeros(2 * self.hh_npad_t * self.hh_ldw_t + SLACK, dtype=tdt, device=dev)
         self.bhh = torch.zeros(2 * 3 * H, dtype=torch.float32, device=dev)
         # fast recurrent path (zs_amd.h: zs_gru_fwd): rows of W_hh gate-interleaved per 32 hidden units
@@ -249,10 +251,10 @@ class GruLayer(object):
             L.call('zs_pack_weight', 'ZsPackWeight', c.stream, transpose=1, inner_pad=3 * H, dst=L.ptr(self.wih_d),
                    ldw=self.ih_ldw_d, n_rows=self.ih_npad_d, n_cols=3 * H, col_offset=3 * H * d, **com)
             com = dict(dtype=c.dt, so=H, si=1, sj=0, Cout=3 * H, Cin=H, taps=1, co_split2=0, W=L.ptr(self.w_hh[d]))
-            L.call('zs_pack_weight', 'ZsPackWeight', c.stream, transpose=0, inner_pad=rup(H, 32),
+            L.call('zs_pack_weight', 'ZsPackWeight', c.stream, transpose=0, inner_pad=rup(H, c.kc),
                    dst=L.ptr(self.whh_f, d * self.hh_npad * self.hh_ldw), ldw=self.hh_ldw,
                    n_rows=(3 * H if self.fast else self.hh_npad), n_cols=self.hh_ldw, row_perm=L.ptr(self.perm), **com)
-            L.call('zs_pack_weight', 'ZsPackWeight', c.stream, transpose=1, inner_pad=rup(3 * H, 32),
+            L.call('zs_pack_weight', 'ZsPackWeight', c.stream, transpose=1, inner_pad=rup(3 * H, c.kc),
                    dst=L.ptr(self.whh_t, d * self.hh_npad_t * self.hh_ldw_t), ldw=self.hh_ldw_t, n_rows=self.hh_npad_t,
                    n_cols=self.hh_ldw_t, **com)
             self.bih[3 * H * d:3 * H * (d + 1)].copy_(self.b_ih[d])
@@ -269,7 +271,7 @@ class GruLayer(object):
         L.call('zs_gemm_conv', 'ZsGemmConv', c.stream, dtype=c.dt, A=X.ptr(), lda=X.ld, a_batch_stride=X.T * X.ld, B=X.B,
                T_in=X.T, T_out=X.T, taps=1, stride=1, pad_left=0, pad_mode=L.ZS_PAD_ZERO, gather=0, cin_pad=self.cin_pad,
                W=L.ptr(self.wih_f), ldw=self.ih_ldw, N=6 * H, n_pad=self.ih_npad, bias=L.ptr(self.bih), act=L.ZS_ACT_NONE,
-               out=gi.ptr(), ldc=gi.ld, out_cols=min(gi.cols, self.g6_pad), groups=1)
+               out=gi.ptr(), ldc=gi.ld, out_cols=min(gi.cols, rup(6 * H, 32)), groups=1)
         work = self._work(X.B)
         L.call('zs_gru_fwd', 'ZsGruFwd', c.stream, dtype=c.dt, B=X.B, T=X.T, H=H, gi=gi.ptr(), ldgi=gi.ld,
                whh=L.ptr(self.whh_f), ldw=self.hh_ldw, n_pad=self.hh_npad, w_gstride=self.hh_npad * self.hh_ldw,
@@ -301,7 +303,7 @@ class GruLayer(object):
         kw = dict(dtype=c.dt, A=dgi.ptr(), lda=dgi.ld, a_batch_stride=T * dgi.ld, B=B, T_in=T, T_out=T, taps=1, stride=1,
                   pad_left=0, pad_mode=L.ZS_PAD_ZERO, gather=0, cin_pad=self.g6_pad, W=L.ptr(self.wih_d), ldw=self.ih_ldw_d,
                   N=self.Cin, n_pad=self.ih_npad_d, act=L.ZS_ACT_NONE, out=dX.ptr(), ldc=dX.ld,
-                  out_cols=min(dX.cols, self.cin_pad), groups=1)
+                  out_cols=min(dX.cols, rup(self.Cin, 32)), groups=1)
         if add_src is not None:
             kw.update(add_src=add_src.ptr(), add_ld=add_src.ld, add_f32=0)
         L.call('zs_gemm_conv', 'ZsGemmConv', c.stream, **kw)
