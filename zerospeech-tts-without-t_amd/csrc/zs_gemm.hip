@@ -16,6 +16,8 @@
 //  * Accumulator layout (32x32): col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); lanes run
 //    along the output channel, so each store instruction writes 32 consecutive channels of a row.
 //  * blockIdx -> tile map is XCD-aware (consecutive tiles of one M panel share an XCD's L2).
+#include <stdlib.h>
+
 #include "zs_common.h"
 
 namespace {
@@ -63,6 +65,178 @@ template <> struct Mma<float> {
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
   }
 };
+
+// ------------------------------------------------------------------------------------------------
+// Epilogue.  The accumulators are first transposed through LDS (static register indices, 64 ds_write_b32 per
+// lane), then a COMPACT rolled loop finishes the tile with each thread owning 8 consecutive columns of a row:
+// 16-byte loads of the mask / residual operands and 16-byte stores (a fully unrolled per-accumulator epilogue
+// was ~15k instructions executed once per tile -- instruction-fetch bound, ~22 us per tile -- with 2-byte
+// stores).  Order: +bias -> +pre_vec[b] -> act -> *lrelu'(dact_src) -> +add_src -> store out / out2(+vec2[b]).
+// ------------------------------------------------------------------------------------------------
+constexpr int CPITCH = 132;                       // fp32 row pitch of the staged tile
+constexpr int EPI_LDS_BYTES = BM * CPITCH * 4;    // 67,584 B
+
+template <typename T, typename OT>
+__device__ __forceinline__ void store_group(OT* base, int64_t row, int64_t ld, int col, int limit, bool aligned,
+                                            const float (&v)[8]) {
+  OT* d = base + row * ld + col;
+  if (aligned && col + 8 <= limit) {
+    store8<OT>(d, v);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (col + j < limit) Elem<OT>::st(d + j, v[j]);
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void gemm_epilogue(const ZsGemmConv& p, f32x16 (&acc)[2][2], float* sC, int M, int m0, int n0,
+                                              int wm, int wn, int tid, int g) {
+  const int lane = tid & 63;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int col = wn * 64 + ni * 32 + (lane & 31);
+        sC[row * CPITCH + col] = acc[mi][ni][r];
+      }
+  __syncthreads();
+
+  const int cg = tid & 15, rr0 = tid >> 4;          // 16 column groups x 16 rows per pass, 8 passes
+  const int n = n0 + cg * 8;
+  if (n >= p.N && n >= p.out_cols && n >= p.out2_cols) return;
+  const int half = p.N >> 1;
+  const bool need_b = (p.pre_vec != nullptr) || (p.vec2 != nullptr);
+  const int es = (int)sizeof(T);
+  // alignment of the 8-column groups (pointers and pitches are wave-uniform)
+  const bool al_out = p.out && ((((uintptr_t)p.out) | (uintptr_t)(p.ldc * (p.out_f32 ? 4 : es)) | (uintptr_t)(p.out_gstride * (p.out_f32 ? 4 : es))) & 15) == 0;
+  const bool al_out2 = p.out2 && ((((uintptr_t)p.out2) | (uintptr_t)(p.ldc2 * es)) & 15) == 0;
+  const bool al_dact = p.dact_src && ((((uintptr_t)p.dact_src) | (uintptr_t)(p.dact_ld * es)) & 15) == 0;
+  const bool al_add = p.add_src && ((((uintptr_t)p.add_src) | (uintptr_t)(p.add_ld * (p.add_f32 ? 4 : es))) & 15) == 0;
+  const bool split_ok = (half & 7) == 0;              // an 8-column group never straddles the two pixel-shuffle halves
+  float bias[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bias[j] = (p.bias != nullptr && n + j < p.N) ? p.bias[(int64_t)g * p.bias_gstride + n + j] : 0.f;
+  float* outf = (float*)p.out + (p.out_f32 ? (int64_t)g * p.out_gstride : 0);
+  T* outt = (T*)p.out + (p.out_f32 ? 0 : (int64_t)g * p.out_gstride);
+
+#pragma unroll 1
+  for (int it = 0; it < 8; ++it) {
+    const int row = rr0 + 16 * it;
+    const int m = m0 + row;
+    if (m >= M) break;
+    float v[8];
+    {
+      const float4 x0 = *reinterpret_cast<const float4*>(sC + row * CPITCH + cg * 8);
+      const float4 x1 = *reinterpret_cast<const float4*>(sC + row * CPITCH + cg * 8 + 4);
+      v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+    }
+    int b = 0;
+    if (need_b) b = m / p.T_out;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += bias[j];
+    if (p.pre_vec) {
+      const float* pv = p.pre_vec + p.vec_idx[b] * p.pre_vec_ld + n;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (n + j < p.N) v[j] += pv[j];
+    }
+    if (p.act == ZS_ACT_LRELU) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = lrelu_f(v[j], p.slope);
+    } else if (p.act == ZS_ACT_SIGMOID) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 1.f / (1.f + expf(-v[j]));
+    } else if (p.act == ZS_ACT_TANH) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = tanhf(v[j]);
+    }
+    if (p.dact_src) {
+      const T* dp = (const T*)p.dact_src + (int64_t)m * p.dact_ld + n;
+      float y[8];
+      if (al_dact && n + 8 <= p.N) load8<T>(dp, y);
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = (n + j < p.N) ? Elem<T>::ld(dp + j) : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= dlrelu_f(y[j], p.slope);
+    }
+    if (p.add_src) {
+      float y[8];
+      if (p.add_f32) {
+        const float* ap = (const float*)p.add_src + (int64_t)m * p.add_ld + n;
+        if (al_add && n + 8 <= p.N) load8<float>(ap, y);
+        else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) y[j] = (n + j < p.N) ? ap[j] : 0.f;
+        }
+      } else {
+        const T* ap = (const T*)p.add_src + (int64_t)m * p.add_ld + n;
+        if (al_add && n + 8 <= p.N) load8<T>(ap, y);
+        else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) y[j] = (n + j < p.N) ? Elem<T>::ld(ap + j) : 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += y[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (n + j >= p.N) v[j] = 0.f;      // columns [N, out_cols) are written as zeros
+
+    if (p.out) {
+      if (p.store_mode == ZS_STORE_SPLIT2) {
+        if (split_ok) {
+          const int hi = n >= half;
+          if (p.out_f32) store_group<T, float>(outf, 2 * (int64_t)m + hi, p.ldc, n - hi * half, half, al_out, v);
+          else store_group<T, T>(outt, 2 * (int64_t)m + hi, p.ldc, n - hi * half, half, al_out, v);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (n + j < p.N) {
+              const int hi = (n + j) >= half;
+              const int64_t o = (2 * (int64_t)m + hi) * p.ldc + (n + j - hi * half);
+              if (p.out_f32) outf[o] = v[j]; else Elem<T>::st(outt + o, v[j]);
+            }
+        }
+      } else {
+        if (p.out_f32) store_group<T, float>(outf, m, p.ldc, n, p.out_cols, al_out, v);
+        else store_group<T, T>(outt, m, p.ldc, n, p.out_cols, al_out, v);
+      }
+    }
+    if (p.out2) {
+      const bool sp = p.store_mode2 == ZS_STORE_SPLIT2;
+      if (sp && !split_ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (n + j < p.N) {
+            const int hi = (n + j) >= half;
+            const int oc = n + j - hi * half;
+            float w = v[j];
+            if (p.vec2) w += p.vec2[p.vec_idx[b] * p.vec2_ld + oc];
+            Elem<T>::st((T*)p.out2 + (2 * (int64_t)m + hi) * p.ldc2 + oc, w);
+          }
+      } else {
+        const int hi = sp ? (n >= half) : 0;
+        const int oc = n - hi * half;
+        const int64_t orow = sp ? (2 * (int64_t)m + hi) : (int64_t)m;
+        const int limit = sp ? half : p.out2_cols;
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = v[j];
+        if (p.vec2) {
+          const float* pv = p.vec2 + p.vec_idx[b] * p.vec2_ld + oc;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (n + j < p.N) w[j] += pv[j];
+        }
+        store_group<T, T>((T*)p.out2, orow, p.ldc2, oc, limit, al_out2, w);
+      }
+    }
+  }
+}
 
 template <typename T>
 __global__ __launch_bounds__(NT, 2) void gemm_conv_kernel(const ZsGemmConv p) {
@@ -194,60 +368,137 @@ __global__ __launch_bounds__(NT, 2) void gemm_conv_kernel(const ZsGemmConv p) {
 #undef ZS_SWRITE
 #undef ZS_SET_TAP
 
-  // ---- epilogue ----
-  const bool need_b = (p.pre_vec != nullptr) || (p.vec2 != nullptr);
-  const int half = p.N >> 1;
-  float* outf = (float*)p.out + (p.out_f32 ? (int64_t)g * p.out_gstride : 0);
-  T* outt = (T*)p.out + (p.out_f32 ? 0 : (int64_t)g * p.out_gstride);
+  gemm_epilogue<T>(p, acc, reinterpret_cast<float*>(smem), M, m0, n0, wm, wn, tid, g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the same GEMM: operand chunks go global -> LDS directly (global_load_lds_dwordx4, 1 KiB
+// per wave-instruction = 8 tile rows x 128 B), no VGPR staging and no ds_write (ds_write_b128 sustains only
+// ~79 B/clk/CU, which costs as much LDS-pipe time as the MFMAs of this tile).  The LDS image is lane-linear
+// (unpadded 128-byte rows), so bank conflicts are removed by an XOR swizzle applied to the SOURCE segment:
+// physical 16-byte slot s' of row r holds logical segment s' ^ ((r >> 1) & 7); fragment reads apply the same
+// XOR.  For the 16 rows of a ds_read_b128 lane group the slot index 8*(r&1) + (s ^ ((r>>1)&7)) is a bijection.
+// ------------------------------------------------------------------------------------------------
+constexpr int DTILE = 128 * 128;   // bytes per operand tile
+
+template <typename T>
+__global__ __launch_bounds__(NT, 2) void gemm_conv_dma_kernel(const ZsGemmConv p) {
+  constexpr int EPS = 16 / (int)sizeof(T);
+  constexpr int KC = ROWB / (int)sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sA = smem;                 // [2][DTILE]
+  unsigned char* sB = smem + 2 * DTILE;     // [2][DTILE]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g = blockIdx.z;
+  const T* __restrict__ A = (const T*)p.A + (int64_t)g * p.a_gstride;
+  const T* __restrict__ W = (const T*)p.W + (int64_t)g * p.w_gstride;
+  const int M = p.B * p.T_out;
+  const int ntn = (p.N + BN - 1) / BN;
+  const int ntm = (M + BM - 1) / BM;
+  const int wg = xcd_remap(blockIdx.x, ntm * ntn);
+  constexpr int GM = 8;
+  const int per_group = GM * ntn;
+  const int grp = wg / per_group;
+  const int gm = min(GM, ntm - grp * GM);
+  const int in_g = wg - grp * per_group;
+  const int m0 = (grp * GM + in_g % gm) * BM, n0 = (in_g / gm) * BN;
+
+  // loader: wave-instruction i of this wave fills tile rows wave*32 + 8i .. +7 (lane>>3 selects the row,
+  // lane&7 the physical slot); the logical segment it must fetch is slot ^ ((row>>1)&7)
+  const int lrow = lane >> 3, slot = lane & 7;
+  int rb[4], rt[4], lseg[4];
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int n = n0 + wn * 64 + ni * 32 + (lane & 31);
-    const bool nvalid = n < p.N;
-    const float bias = (p.bias != nullptr && nvalid) ? p.bias[(int64_t)g * p.bias_gstride + n] : 0.f;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m >= M) continue;
-        float v = 0.f;
-        int b = 0;
-        if (need_b) b = m / p.T_out;
-        if (nvalid) {
-          v = acc[mi][ni][r] + bias;
-          if (p.pre_vec) v += p.pre_vec[p.vec_idx[b] * p.pre_vec_ld + n];
-          if (p.act == ZS_ACT_LRELU) v = lrelu_f(v, p.slope);
-          else if (p.act == ZS_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
-          else if (p.act == ZS_ACT_TANH) v = tanhf(v);
-          if (p.dact_src) v *= dlrelu_f(Elem<T>::ld((const T*)p.dact_src + (int64_t)m * p.dact_ld + n), p.slope);
-          if (p.add_src) {
-            v += p.add_f32 ? ((const float*)p.add_src)[(int64_t)m * p.add_ld + n]
-                           : Elem<T>::ld((const T*)p.add_src + (int64_t)m * p.add_ld + n);
-          }
-        }
-        if (p.out) {
-          int64_t orow = m; int ocol = n; bool st = n < p.out_cols;
-          if (p.store_mode == ZS_STORE_SPLIT2) {
-            const int hi = n >= half; orow = 2 * (int64_t)m + hi; ocol = n - hi * half; st = nvalid;
-          }
-          if (st) {
-            if (p.out_f32) outf[orow * p.ldc + ocol] = v; else Elem<T>::st(outt + orow * p.ldc + ocol, v);
-          }
-        }
-        if (p.out2) {
-          int64_t orow = m; int ocol = n; bool st = n < p.out2_cols;
-          if (p.store_mode2 == ZS_STORE_SPLIT2) {
-            const int hi = n >= half; orow = 2 * (int64_t)m + hi; ocol = n - hi * half; st = nvalid;
-          }
-          if (st) {
-            float v2 = v;
-            if (p.vec2 && nvalid) v2 += p.vec2[p.vec_idx[b] * p.vec2_ld + ocol];
-            Elem<T>::st((T*)p.out2 + orow * p.ldc2 + ocol, v2);
-          }
-        }
-      }
-    }
+  for (int i = 0; i < 4; ++i) {
+    const int r = wave * 32 + i * 8 + lrow;
+    lseg[i] = slot ^ ((r >> 1) & 7);
+    const int m = m0 + r;
+    if (m < M) { rb[i] = m / p.T_out; rt[i] = m - rb[i] * p.T_out; } else { rb[i] = -1; rt[i] = 0; }
   }
+  const int chunks_per_tap = p.cin_pad / KC;
+  const T* zline = reinterpret_cast<const T*>(zs_zero_line);
+  const T *pa0, *pa1, *pa2, *pa3;
+  int inc0, inc1, inc2, inc3;
+#define ZS_SET_TAP(i, ptr, inc)                                                                         \
+  {                                                                                                     \
+    bool ok = false; int srow = 0;                                                                      \
+    if (rb[i] >= 0) srow = conv_src_row(p.gather, p.pad_mode, p.stride, p.pad_left, p.T_in, rt[i], tap, ok); \
+    ptr = ok ? (A + (int64_t)rb[i] * p.a_batch_stride + (int64_t)srow * p.lda + lseg[i] * EPS) : (zline + lseg[i] * EPS); \
+    inc = ok ? KC : 0;                                                                                  \
+  }
+  const T* pw0 = W + (int64_t)(n0 + wave * 32 + lrow) * p.ldw + lseg[0] * EPS;
+  const T* pw1 = W + (int64_t)(n0 + wave * 32 + 8 + lrow) * p.ldw + lseg[1] * EPS;
+  const T* pw2 = W + (int64_t)(n0 + wave * 32 + 16 + lrow) * p.ldw + lseg[2] * EPS;
+  const T* pw3 = W + (int64_t)(n0 + wave * 32 + 24 + lrow) * p.ldw + lseg[3] * EPS;
+  const int nk = p.taps * chunks_per_tap;
+  int tap = 0, cit = 0;
+  { ZS_SET_TAP(0, pa0, inc0) ZS_SET_TAP(1, pa1, inc1) ZS_SET_TAP(2, pa2, inc2) ZS_SET_TAP(3, pa3, inc3) }
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto dma = [&](int buf) {
+    unsigned char* da = sA + buf * DTILE + wave * 4096;   // this wave's 32 rows
+    unsigned char* db = sB + buf * DTILE + wave * 4096;
+    __builtin_amdgcn_global_load_lds((gptr_t)pa0, (lptr_t)(da), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)pa1, (lptr_t)(da + 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)pa2, (lptr_t)(da + 2048), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)pa3, (lptr_t)(da + 3072), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)pw0, (lptr_t)(db), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)pw1, (lptr_t)(db + 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)pw2, (lptr_t)(db + 2048), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)pw3, (lptr_t)(db + 3072), 16, 0, 0);
+    pw0 += KC; pw1 += KC; pw2 += KC; pw3 += KC;
+    if (++cit == chunks_per_tap) {
+      cit = 0; ++tap;
+      if (tap < p.taps) { ZS_SET_TAP(0, pa0, inc0) ZS_SET_TAP(1, pa1, inc1) ZS_SET_TAP(2, pa2, inc2) ZS_SET_TAP(3, pa3, inc3) }
+    } else {
+      pa0 += inc0; pa1 += inc1; pa2 += inc2; pa3 += inc3;
+    }
+  };
+#undef ZS_SET_TAP
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addresses: row = w*64 + mi*32 + (lane&31); logical segment 2*ks + (lane>>5); slot = seg ^ ((row>>1)&7)
+  const int frow = lane & 31, fh = lane >> 5;
+  const int fx = (frow >> 1) & 7;             // same for row and row+32 (32>>1 = 16, &7 = 0)
+  dma(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    // 1) all fragments of chunk kt into registers FIRST: hipcc orders any ds_read that follows an LDS-DMA behind
+    //    vmcnt(0) (it cannot tell the two buffers apart), which would serialise the DMA with the MFMAs
+    const unsigned char* a_base = sA + buf * DTILE + (wm * 64 + frow) * 128;
+    const unsigned char* b_base = sB + buf * DTILE + (wn * 64 + frow) * 128;
+    uint4 fa[4][2], fb[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int off = ((2 * ks + fh) ^ fx) * 16;
+      fa[ks][0] = *reinterpret_cast<const uint4*>(a_base + off);
+      fa[ks][1] = *reinterpret_cast<const uint4*>(a_base + 32 * 128 + off);
+      fb[ks][0] = *reinterpret_cast<const uint4*>(b_base + off);
+      fb[ks][1] = *reinterpret_cast<const uint4*>(b_base + 32 * 128 + off);
+    }
+    // 2) chunk kt+1 straight into the other buffer (every wave passed the barrier: nobody reads it any more)
+    if (kt + 1 < nk) dma(buf ^ 1);
+    // 3) MFMAs run while the DMA is in flight
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) Mma<T>::run(fa[ks][mi], fb[ks][ni], acc[mi][ni]);
+    __builtin_amdgcn_sched_barrier(0);                 // keep the MFMAs above the wait (register-only ops float past asm)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
+    __syncthreads();                                   // ... and everyone else's
+  }
+  gemm_epilogue<T>(p, acc, reinterpret_cast<float*>(smem), M, m0, n0, wm, wn, tid, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -504,10 +755,17 @@ extern "C" int zs_gemm_conv(const ZsGemmConv* p, void* stream) {
   const int64_t tiles = ((M + BM - 1) / BM) * ((p->N + BN - 1) / BN);
   ZS_REQUIRE(tiles < (1ll << 31), "zs_gemm_conv: grid too large");
   dim3 grid((unsigned)tiles, 1, (unsigned)groups);
-  const size_t lds = 4 * TILE_BYTES;
   hipStream_t s = (hipStream_t)stream;
-  if (p->dtype == ZS_F32) hipLaunchKernelGGL(gemm_conv_kernel<float>, grid, dim3(NT), lds, s, *p);
-  else hipLaunchKernelGGL(gemm_conv_kernel<bf16_t>, grid, dim3(NT), lds, s, *p);
+  static const int use_dma = [] { const char* e = getenv("ZS_GEMM_DMA"); return e ? atoi(e) : 1; }();
+  if (use_dma) {
+    const size_t lds = (4 * DTILE > EPI_LDS_BYTES) ? 4 * DTILE : EPI_LDS_BYTES;
+    if (p->dtype == ZS_F32) hipLaunchKernelGGL(gemm_conv_dma_kernel<float>, grid, dim3(NT), lds, s, *p);
+    else hipLaunchKernelGGL(gemm_conv_dma_kernel<bf16_t>, grid, dim3(NT), lds, s, *p);
+  } else {
+    const size_t lds = 4 * TILE_BYTES;
+    if (p->dtype == ZS_F32) hipLaunchKernelGGL(gemm_conv_kernel<float>, grid, dim3(NT), lds, s, *p);
+    else hipLaunchKernelGGL(gemm_conv_kernel<bf16_t>, grid, dim3(NT), lds, s, *p);
+  }
   return zs_check_launch("zs_gemm_conv");
 }
 
