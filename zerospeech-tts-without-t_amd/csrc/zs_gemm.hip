@@ -532,28 +532,49 @@ template <> struct WFrag<float> {
   }
 };
 template <> struct WFrag<bf16_t> {
-  static constexpr int PITCHW = 128 * 2 + 16;
-  // chunk of 32 rows -> 2 steps of v_mfma_f32_32x32x16_bf16 (k = 16*step + 8*(lane>>5) + j)
+  // 320-byte rows: for ds_read_b64_tr_b16 the four row addresses of a 16-lane group start 80 dwords apart
+  // (0,16,32,48 mod 64) and the second group of a 32-lane half is 8 dwords further: conflict free.
+  static constexpr int PITCHW = 128 * 2 + 64;
+  // chunk of 32 rows -> 2 steps of v_mfma_f32_32x32x16_bf16.  Both operands are K(=row)-strided in LDS, so the
+  // fragments come from the hardware transposing read: per 16-lane group, lane 4q+p supplies the address of row
+  // q, columns 4p..4p+3 of a 4-row x 16-column block and lane i receives column i of those 4 rows.  A lane's
+  // 8 k-values (k = 8*(lane>>5) + j) are two such reads (rows kb..kb+3, kb+4..kb+7); 2 LDS instructions per
+  // fragment instead of 8 ds_read_u16.  EXEC is all ones here (uniform control flow, 256-thread blocks).
   static __device__ __forceinline__ void chunk(const unsigned char* sY, const unsigned char* sX, int wm, int wn, int lane,
                                                f32x16 (&acc)[2][2]) {
-    const int r = lane & 31, h = lane >> 5;
+    const int grp = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+    const int cb = 16 * (grp & 1), kb = 8 * (grp >> 1);
+    const unsigned ya = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)sY +
+                        (unsigned)((kb + q) * PITCHW + (wm * 64 + cb + 4 * pp) * 2);
+    const unsigned xa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)sX +
+                        (unsigned)((kb + q) * PITCHW + (wn * 64 + cb + 4 * pp) * 2);
+    uint2 ra[2][2][2], rb[2][2][2];            // [k-step][32-wide tile][row half]
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+          const unsigned off = (unsigned)((16 * st + 4 * hb) * PITCHW + t * 64);
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ra[st][t][hb]) : "v"(ya + off));
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(rb[st][t][hb]) : "v"(xa + off));
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);         // MFMAs (register-only) must not be hoisted above the wait
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
-      bf16x8 a[2], b[2];
+      uint4 fa[2], fb[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int k = 16 * st + 8 * h + j;
-          a[i][j] = __builtin_bit_cast(__bf16, *reinterpret_cast<const bf16_t*>(sY + k * PITCHW + (wm * 64 + i * 32 + r) * 2));
-          b[i][j] = __builtin_bit_cast(__bf16, *reinterpret_cast<const bf16_t*>(sX + k * PITCHW + (wn * 64 + i * 32 + r) * 2));
-        }
+      for (int t = 0; t < 2; ++t) {
+        fa[t] = make_uint4(ra[st][t][0].x, ra[st][t][0].y, ra[st][t][1].x, ra[st][t][1].y);
+        fb[t] = make_uint4(rb[st][t][0].x, rb[st][t][0].y, rb[st][t][1].x, rb[st][t][1].y);
       }
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[mi]), __builtin_bit_cast(bf16x8, fb[ni]),
+                                                                acc[mi][ni], 0, 0, 0);
     }
   }
 };
@@ -674,18 +695,32 @@ __global__ __launch_bounds__(NT, 2) void gemm_wgrad_kernel(const ZsGemmWgrad p, 
       bslab[co0 + tid] = t;
     }
   }
-  // slab[split][co][tap][ci], co < cout_r, ci < cin_r (full tiles: no guards needed)
+  // slab[split][co][tap][ci], co < cout_r, ci < cin_r (full tiles: no guards needed).  Accumulators are restaged
+  // through LDS so that each thread stores 8 consecutive ci (two 16-byte stores) of a co row.
   float* slab = (float*)p.workspace + (int64_t)blockIdx.y * cout_r * p.taps * cin_r;
+  float* sC = reinterpret_cast<float*>(smem);
+  __syncthreads();                                  // bias reduction above (if any) is done with LDS
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = co0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int ci = ci0 + wn * 64 + ni * 32 + (lane & 31);
-        slab[((int64_t)co * p.taps + tap) * cin_r + ci] = acc[mi][ni][r];
+        const int row = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int col = wn * 64 + ni * 32 + (lane & 31);
+        sC[row * CPITCH + col] = acc[mi][ni][r];
       }
+  __syncthreads();
+  const int cg = tid & 15, rr0 = tid >> 4;
+#pragma unroll 1
+  for (int it = 0; it < 8; ++it) {
+    const int row = rr0 + 16 * it;
+    const float4 x0 = *reinterpret_cast<const float4*>(sC + row * CPITCH + cg * 8);
+    const float4 x1 = *reinterpret_cast<const float4*>(sC + row * CPITCH + cg * 8 + 4);
+    float* d = slab + ((int64_t)(co0 + row) * p.taps + tap) * cin_r + ci0 + cg * 8;
+    *reinterpret_cast<float4*>(d) = x0;
+    *reinterpret_cast<float4*>(d + 4) = x1;
+  }
 }
 
 __global__ void wgrad_reduce_kernel(const ZsGemmWgrad p, int splits, int cout_r, int cin_r) {
@@ -777,6 +812,7 @@ extern "C" size_t zs_gemm_wgrad_workspace_bytes(const ZsGemmWgrad* p) {
 
 extern "C" int zs_gemm_wgrad(const ZsGemmWgrad* p, void* stream) {
   ZS_REQUIRE(p && p->dY && p->X && p->dW && p->workspace, "zs_gemm_wgrad: null operand");
+  ZS_REQUIRE(aligned16(p->workspace), "zs_gemm_wgrad: workspace must be 16-byte aligned");
   ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_gemm_wgrad: bad dtype");
   const int es = p->dtype == ZS_F32 ? 4 : 2;
   ZS_REQUIRE(p->B > 0 && p->T_in > 0 && p->T_out > 0 && p->Cout > 0 && p->Cin > 0 && p->taps > 0 && p->stride > 0,
@@ -800,10 +836,10 @@ extern "C" int zs_gemm_wgrad(const ZsGemmWgrad* p, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)(co_tiles * p->taps * ci_tiles), (unsigned)splits, 1);
   if (p->dtype == ZS_F32) {
-    const size_t lds = 4 * WK * WFrag<float>::PITCHW;
+    const size_t lds = (4 * WK * WFrag<float>::PITCHW > EPI_LDS_BYTES) ? 4 * WK * WFrag<float>::PITCHW : EPI_LDS_BYTES;
     hipLaunchKernelGGL(gemm_wgrad_kernel<float>, grid, dim3(NT), lds, s, *p, ci_tiles, rows_per_split, cout_r, cin_r);
   } else {
-    const size_t lds = 4 * WK * WFrag<bf16_t>::PITCHW;
+    const size_t lds = (4 * WK * WFrag<bf16_t>::PITCHW > EPI_LDS_BYTES) ? 4 * WK * WFrag<bf16_t>::PITCHW : EPI_LDS_BYTES;
     hipLaunchKernelGGL(gemm_wgrad_kernel<bf16_t>, grid, dim3(NT), lds, s, *p, ci_tiles, rows_per_split, cout_r, cin_r);
   }
   int rc = zs_check_launch("zs_gemm_wgrad");
