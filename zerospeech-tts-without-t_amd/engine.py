@@ -162,10 +162,10 @@ class EncoderEngine(object):
         for j in (1, 0):
             la, lb = self.dense[j]
             xin, d1, d2, stt = tp['dense'][j]
-            dz2 = c.act('e_dz2' + tag, B, T4, c2)
+            dz2 = c.act('e_dz2%d' % j + tag, B, T4, c2)          # unique per block: read later by the side-stream wgrad
             self._in_bwd(da, d2, stt, dz2, tp)
             lb.wgrad(dz2, d1)
-            dz1 = c.act('e_dz1' + tag, B, T4, c2)
+            dz1 = c.act('e_dz1%d' % j + tag, B, T4, c2)
             lb.dgrad(dz2, T4, dz1, dact_src=d1, slope=ns)
             la.wgrad(dz1, xin)
             dn = c.act('e_da_d%d' % j + tag, B, T4, c2)
@@ -340,11 +340,11 @@ class DecoderEngine(object):
         for j in (1, 0):
             la, lb = self.dense[j]
             xin, xe, y1, y1e, y2, stt = tp['dense'][j]
-            dz2 = c.act('d_dz2' + tag, B, T, ch)
+            dz2 = c.act('d_dz2%d' % j + tag, B, T, ch)           # unique per block: read later by the side-stream wgrad
             self._in_bwd(dx, y2, stt, dz2)
             lb.wgrad(dz2, y1e)
             lb.dgrad(dz2, T, gpv)
-            dz1 = c.act('d_dz1' + tag, B, T, ch)
+            dz1 = c.act('d_dz1%d' % j + tag, B, T, ch)
             self._combine(gpv, T, 0, 0, dz1, emb_i=3, dact=y1)
             la.wgrad(dz1, xe)
             la.dgrad(dz1, T, gpv)

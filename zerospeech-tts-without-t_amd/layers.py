@@ -1,6 +1,7 @@
 """Host-side description of the GEMM-shaped layers: operand packing and the forward / data-gradient /
 weight-gradient calls into libzs_amd.so.  PyTorch is used for device memory only."""
 import ctypes
+import os
 
 import torch
 
@@ -44,6 +45,27 @@ class Act(object):
         return torch.as_strided(base, (self.B, self.T, self.C), (self.T * self.ld, self.ld, 1))
 
 
+_SIDE = {}
+
+
+def side_stream(device):
+    """One extra HIP stream per device for work that is off the critical path (weight gradients)."""
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = {'stream': torch.cuda.Stream(device), 'used': False}
+    return _SIDE[key]
+
+
+def join_side(device):
+    """Make the current stream wait for everything enqueued on the side stream."""
+    sd = side_stream(device)
+    if sd['used']:
+        ev = torch.cuda.Event()
+        ev.record(sd['stream'])
+        torch.cuda.current_stream(device).wait_event(ev)
+        sd['used'] = False
+
+
 class Ctx(object):
     """Per-model execution context: device, compute dtype, cached buffers, split-K workspace."""
 
@@ -60,6 +82,9 @@ class Ctx(object):
         self.kc = 128 // self.es
         self._bufs = {}
         self._ws = None
+        # weight gradients are only needed by the optimizer: run them on a second stream under the latency-bound
+        # phases of the backward chain (GRU steps, small norms)
+        self.overlap_wgrad = os.environ.get('ZS_OVERLAP_WGRAD', '1') == '1'
 
     @property
     def stream(self):
@@ -83,6 +108,8 @@ class Ctx(object):
 
     def workspace(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes:
+            if self._ws is not None:
+                torch.cuda.synchronize(self.device)      # the side stream may still be using the old buffer (rare: growth)
             self._ws = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=self.device)
         return self._ws
 
@@ -195,7 +222,17 @@ def wgrad_call(ctx, kw):
     ws = ctx.workspace(need)
     s.workspace = ws.data_ptr()
     s.workspace_bytes = ws.numel()
-    L.check(L.lib().zs_gemm_wgrad(ctypes.byref(s), ctypes.c_void_p(ctx.stream)), 'zs_gemm_wgrad')
+    stream = ctx.stream
+    if ctx.overlap_wgrad:
+        # ordered after everything enqueued so far on the main stream (dY and X are complete), then asynchronous;
+        # all weight gradients serialise on the side stream, so they can share the split-K workspace
+        sd = side_stream(ctx.device)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(ctx.device))
+        sd['stream'].wait_event(ev)
+        sd['used'] = True
+        stream = sd['stream'].cuda_stream
+    L.check(L.lib().zs_gemm_wgrad(ctypes.byref(s), ctypes.c_void_p(stream)), 'zs_gemm_wgrad')
 
 
 class GruLayer(object):

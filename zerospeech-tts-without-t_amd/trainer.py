@@ -17,7 +17,7 @@ import torch
 
 from . import _lib as L
 from . import parallel
-from .layers import Act
+from .layers import Act, join_side
 from .model import Decoder, Encoder
 from .utils import Logger
 
@@ -62,10 +62,15 @@ class AEStep(object):
                rows=B * xdec.T, F=F, dlogits=dlogit.ptr(), ldg=dlogit.ld, fill_cols=dlogit.ld, partial=L.ptr(self._lpart),
                loss_out=L.ptr(self._loss), grad_scale=1.0)                                   # trainer.py:328
         dbits = de.backward(dlogit)                                                          # loss.backward(), trainer.py:330
-        self.reducer.start(dec.flat_params()[1])
+        multi = parallel.world_size() > 1
+        if multi:
+            join_side(self.device)                 # decoder weight gradients (side stream) must be complete
+            self.reducer.start(dec.flat_params()[1])
         ee.backward(dbits)
-        self.reducer.start(enc.flat_params()[1])
-        self.reducer.finish()
+        join_side(self.device)
+        if multi:
+            self.reducer.start(enc.flat_params()[1])
+            self.reducer.finish()
         self.xdec = xdec
         if update:
             self.optimizer_step()
