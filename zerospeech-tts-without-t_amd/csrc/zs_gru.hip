@@ -134,25 +134,29 @@ template <> struct Frag16<float> {
   }
 };
 
+constexpr int RB = 2;                                  // 16-row blocks per workgroup (32 rows): W is re-read B/32 times per step
+
 template <typename T, int NT16, bool GRU>
 __global__ __launch_bounds__(256) void rowblock_gemm_kernel(const RowGemmArgs a) {
-  // workgroup = one 16-row x (16*NT16)-column tile; its 4 waves split K and reduce through LDS
+  // workgroup = one (16*RB)-row x (16*NT16)-column tile; its 4 waves split K and reduce through LDS
   constexpr int KSTEP = Frag16<T>::KSTEP;
   constexpr int EPL = 16 / (int)sizeof(T);            // elements per lane per fragment
-  __shared__ float part[4][NT16][4][64];               // [wave][tile][reg][lane]
+  constexpr int ROWS = 16 * RB;
+  __shared__ float part[4][RB][NT16][4][64];           // [wave][row block][tile][reg][lane]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, r = lane & 15;
   const int g = blockIdx.z;
-  const int m0 = blockIdx.y * 16;
+  const int m0 = blockIdx.y * ROWS;
   const int n0 = blockIdx.x * (16 * NT16);
-  const int row = m0 + r;
-  const bool rvalid = row < a.M;
   const bool skip = GRU && (a.gate.step == 0);         // h_{-1} = 0
 
   // ---- GRU epilogue operands: issue their loads first so they fly under the K loop ----
-  // thread -> 2 (row, unit) pairs: unit u = tid & 31, rows e_row and e_row + 8
+  // thread -> (row, unit) pairs: unit u = tid & 31, rows e_row + 8*pz
+  constexpr int NP = ROWS / 8;
   const int eu = tid & 31, e_row = tid >> 5;
-  float e_gi[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, e_hp[2] = {0.f, 0.f}, e_b[3] = {0.f, 0.f, 0.f};
+  float e_gi[NP][3], e_hp[NP], e_b[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int pz = 0; pz < NP; ++pz) { e_gi[pz][0] = e_gi[pz][1] = e_gi[pz][2] = 0.f; e_hp[pz] = 0.f; }
   int e_t = 0;
   if constexpr (GRU) {
     const GateFwdArgs& ga = a.gate;
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(256) void rowblock_gemm_kernel(const RowGemmArgs a)
     const float* bh = ga.bhh + (int64_t)d * ga.bhh_gstride;
     e_b[0] = bh[j]; e_b[1] = bh[H + j]; e_b[2] = bh[2 * H + j];
 #pragma unroll
-    for (int pz = 0; pz < 2; ++pz) {
+    for (int pz = 0; pz < NP; ++pz) {
       const int b = m0 + e_row + 8 * pz;
       if (b < a.M) {
         const T* gi = (const T*)ga.gi + ((int64_t)b * ga.T + e_t) * ga.ldgi + (int64_t)d * 3 * H;
@@ -171,55 +175,74 @@ __global__ __launch_bounds__(256) void rowblock_gemm_kernel(const RowGemmArgs a)
     }
   }
 
-  f32x4_t acc[NT16];
+  f32x4_t acc[RB][NT16];
 #pragma unroll
-  for (int c = 0; c < NT16; ++c) acc[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int c = 0; c < NT16; ++c) acc[rb][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   if (!skip) {
-    const T* Arow = (const T*)a.A + (int64_t)g * a.a_gstride + (int64_t)(rvalid ? row : m0) * a.a_row_stride + q * EPL;
+    const T* Arow[RB];
+    bool rvalid[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int row = m0 + 16 * rb + r;
+      rvalid[rb] = row < a.M;
+      Arow[rb] = (const T*)a.A + (int64_t)g * a.a_gstride + (int64_t)(rvalid[rb] ? row : 0) * a.a_row_stride + q * EPL;
+    }
     const T* Wrow = (const T*)a.W + (int64_t)g * a.w_gstride + (int64_t)(n0 + r) * a.ldw + q * EPL;
     const int nks = a.K / KSTEP;
     const int per = (nks + 3) >> 2;
     int ks = wave * per;
     const int kend = min(nks, ks + per);
     for (; ks + 4 <= kend; ks += 4) {                  // 4 k-steps of fragments in flight before the first MFMA
-      uint4 fa[4], fb[4][NT16];
+      uint4 fa[4][RB], fb[4][NT16];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        fa[u] = *reinterpret_cast<const uint4*>(Arow + (ks + u) * KSTEP);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) fa[u][rb] = *reinterpret_cast<const uint4*>(Arow[rb] + (ks + u) * KSTEP);
 #pragma unroll
         for (int c = 0; c < NT16; ++c) fb[u][c] = *reinterpret_cast<const uint4*>(Wrow + (int64_t)(16 * c) * a.ldw + (ks + u) * KSTEP);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (!rvalid) fa[u] = make_uint4(0, 0, 0, 0);
+      for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int c = 0; c < NT16; ++c) Frag16<T>::mma(fa[u], fb[u][c], acc[c]);
-      }
+        for (int rb = 0; rb < RB; ++rb) {
+          if (!rvalid[rb]) fa[u][rb] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+          for (int c = 0; c < NT16; ++c) Frag16<T>::mma(fa[u][rb], fb[u][c], acc[rb][c]);
+        }
     }
     for (; ks < kend; ++ks) {
-      uint4 fa = *reinterpret_cast<const uint4*>(Arow + ks * KSTEP);
-      if (!rvalid) fa = make_uint4(0, 0, 0, 0);
+      uint4 fa[RB];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        fa[rb] = *reinterpret_cast<const uint4*>(Arow[rb] + ks * KSTEP);
+        if (!rvalid[rb]) fa[rb] = make_uint4(0, 0, 0, 0);
+      }
 #pragma unroll
       for (int c = 0; c < NT16; ++c) {
         const uint4 fb = *reinterpret_cast<const uint4*>(Wrow + (int64_t)(16 * c) * a.ldw + ks * KSTEP);
-        Frag16<T>::mma(fa, fb, acc[c]);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) Frag16<T>::mma(fa[rb], fb, acc[rb][c]);
       }
     }
   }
 #pragma unroll
-  for (int c = 0; c < NT16; ++c)
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) part[wave][c][i][lane] = acc[c][i];
+    for (int c = 0; c < NT16; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) part[wave][rb][c][i][lane] = acc[rb][c][i];
   __syncthreads();
-  // element (row rr, col cc) of tile c lives at reg i = rr & 3 of lane (rr >> 2) * 16 + cc
+  // element (row rr in [0,ROWS), col cc) of tile c lives at reg i = rr & 3 of lane ((rr & 15) >> 2) * 16 + cc, block rr >> 4
   auto total = [&](int c, int rr, int cc) -> float {
-    const int l = (rr >> 2) * 16 + cc, i = rr & 3;
-    return (part[0][c][i][l] + part[1][c][i][l]) + (part[2][c][i][l] + part[3][c][i][l]);
+    const int rb = rr >> 4, l = ((rr & 15) >> 2) * 16 + cc, i = rr & 3;
+    return (part[0][rb][c][i][l] + part[1][rb][c][i][l]) + (part[2][rb][c][i][l] + part[3][rb][c][i][l]);
   };
   if constexpr (!GRU) {
     float* out = a.out + (int64_t)g * a.out_gstride;
     constexpr int NC = 16 * NT16;
-    for (int e = tid; e < 16 * NC; e += 256) {          // coalesced along the columns
+    for (int e = tid; e < ROWS * NC; e += 256) {        // coalesced along the columns
       const int rr = e / NC, col = e - rr * NC;
       const int m = m0 + rr;
       if (m < a.M) out[(int64_t)m * a.N + n0 + col] = total(col >> 4, rr, col & 15);
@@ -229,7 +252,7 @@ __global__ __launch_bounds__(256) void rowblock_gemm_kernel(const RowGemmArgs a)
     const int d = g, H = ga.H, j = blockIdx.x * 32 + eu;
     const int hh = eu >> 4, cc = eu & 15;
 #pragma unroll
-    for (int pz = 0; pz < 2; ++pz) {
+    for (int pz = 0; pz < NP; ++pz) {
       const int rr = e_row + 8 * pz;
       const int b = m0 + rr;
       if (b >= a.M) continue;
@@ -288,7 +311,7 @@ extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
       GateFwdArgs& g = a.gate;
       g.gi = p->gi; g.ldgi = p->ldgi; g.gh = nullptr; g.bhh = p->bhh; g.bhh_gstride = p->bhh_gstride; g.hstate = hstate;
       g.out = p->out; g.ldo = p->ldo; g.out_col = p->out_col; g.gates = p->gates; g.B = B; g.T = T; g.H = H; g.step = s;
-      dim3 grid(H / 32, (B + 15) / 16, 2);
+      dim3 grid(H / 32, (B + 16 * RB - 1) / (16 * RB), 2);
       if (p->dtype == ZS_F32) hipLaunchKernelGGL((rowblock_gemm_kernel<float, 6, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
       else hipLaunchKernelGGL((rowblock_gemm_kernel<bf16_t, 6, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
       int rc = zs_check_launch("zs_gru_fwd.step");
@@ -356,7 +379,7 @@ extern "C" int zs_gru_bwd(const ZsGruBwd* p, void* stream) {
       a.W = p->whh_t; a.ldw = p->ldw; a.w_gstride = p->w_gstride;
       a.M = B; a.N = H; a.K = 3 * H;
       a.out = dhg; a.out_gstride = (int64_t)B * H;
-      dim3 grid(H / 32, (B + 15) / 16, 2);
+      dim3 grid(H / 32, (B + 16 * RB - 1) / (16 * RB), 2);
       if (p->dtype == ZS_F32) hipLaunchKernelGGL((rowblock_gemm_kernel<float, 2, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
       else hipLaunchKernelGGL((rowblock_gemm_kernel<bf16_t, 2, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
       rc = zs_check_launch("zs_gru_bwd.step");
