@@ -212,10 +212,16 @@ def main():
         'final_loss': loss, 'host_input': bool(args.host_input),
     }
     peak = 2500.0 if args.dtype == 'bf16' else 157.3
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    if args.dtype == 'bf16' and B == 256 and os.path.exists(tpath):
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+        # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); counters cannot be read from inside the process
+        traffic = json.load(open(tpath)).get('traffic_bytes_per_launch')
     if ke.pairs:
         fl, ms, n = ke.summary()
         ach = fl / (ms * 1e-3) / 1e12
-        out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+        out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic, 'traffic_unit': 'bytes/launch',
                            'kernel': 'gemm_conv_kernel<%s>' % ('bf16' if args.dtype == 'bf16' else 'float'),
                            'launches_timed': n, 'avg_launch_ms': ms / n, 'avg_launch_gflop': fl / n / 1e9,
                            'share_of_step': ms / (1e3 * dt)}
