@@ -254,3 +254,92 @@ def test_full_size_properties(dev, dtype):
     assert xd.min().item() >= 0 and xd.max().item() <= 1
     print(dtype, 'losses', ['%.4f' % v for v in [l0] + losses])
     assert losses[-1] < l0
+
+
+def test_speaker_classifier_golden_fp32(dev):
+    """SpeakerClassifier forward, CE loss and every parameter gradient against the reference (golden)."""
+    from zs_amd import _lib as L
+    from zs_amd.model import SpeakerClassifier
+    d, m = load_golden('classifier_small.npz')
+    clf = SpeakerClassifier(c_in=m['c_in'], c_h=m['c_h'], n_class=m['n_class'], dp=0.0, ns=m['ns'], seg_len=m['seg_len'], dtype='fp32').to(dev)
+    clf.load_state_dict(sub_sd(d, 'clf.'))
+    clf.train()
+    x = torch.from_numpy(d['x']).to(dev)
+    logits = clf(x)
+    assert _rel(logits, d['logits']) < 1e-3
+    eng = clf._engine()
+    out = eng.forward(clf.input_act(x.permute(0, 2, 1).contiguous()), True)
+    B = x.shape[0]
+    y = torch.from_numpy(d['y']).to(dev)
+    loss, corr = torch.zeros(1, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    dl = torch.zeros(B, out.ld, device=dev)
+    L.call('zs_softmax_ce', 'ZsSoftmaxCE', torch.cuda.current_stream().cuda_stream, logits=out.ptr(), ld=out.ld, target=L.ptr(y), B=B,
+           n_class=m['n_class'], loss_out=L.ptr(loss), dlogits=L.ptr(dl), ldg=out.ld, grad_scale=1.0, correct_out=L.ptr(corr))
+    eng.backward(dl, out.ld, need_dx=True)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(d['loss'])) < 1e-5
+    assert corr.item() == int((torch.from_numpy(d['logits']).argmax(1) == torch.from_numpy(d['y'])).sum())
+    for k, g in _grad_dict(clf).items():
+        ref = torch.from_numpy(d['g.' + k])
+        scale = ref.abs().max().item()
+        if scale < 1e-6:
+            continue
+        assert (g - ref).abs().max().item() / scale < 2e-3, k
+    assert set(clf.state_dict().keys()) == set(sub_sd(d, 'clf.').keys())
+
+
+def test_adversarial_steps_vs_oracle(dev):
+    """D step (classifier CE) and G step (loss_rec - alpha*loss_clf, trainer.py:444) gradients against the oracle's autograd."""
+    import zs_oracle as O
+    from zs_amd.model import SpeakerClassifier
+    from zs_amd.trainer import AEStep, ClfStep
+    d, m = load_golden('train_f80.npz')
+    enc, dec = _build(m, 'fp32', dev, d, 'enc0.', 'dec0.', dp=0.0)
+    torch.manual_seed(3)
+    clf = SpeakerClassifier(c_in=2 * m['enc_size'], c_h=32, n_class=m['n_spk'], dp=0.0, ns=m['ns'], seg_len=128, dtype='fp32').to(dev)
+    ae = AEStep(enc, dec, lr=1e-4, max_grad_norm=5.0)
+    cs = ClfStep(ae, clf, lr=1e-4, max_grad_norm=5.0)
+    gen = torch.Generator().manual_seed(8)
+    B, T = 3, 128
+    x_bct = torch.rand(B, m['c_in'], T, generator=gen) * 0.98 + 1e-3
+    c = torch.randint(0, m['n_spk'], (B,), generator=gen)
+    G = O.gumbel_from_uniform(torch.rand(B, T // 8, m['enc_size'], 2, generator=gen))
+    alpha = 0.37
+    # oracle
+    esd = {k: v.clone().requires_grad_(True) for k, v in sub_sd(d, 'enc0.').items()}
+    dsd = {k: v.clone().requires_grad_(True) for k, v in sub_sd(d, 'dec0.').items()}
+    csd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in clf.state_dict().items()}
+    act, logits = O.encoder_forward(esd, x_bct, m['ns'], 0.0, m['enc_size'], 128, G=G, training=True)
+    xdec = O.decoder_forward(dsd, act, c, m['ns'], 128)
+    l_rec = O.l1_loss(xdec, x_bct)
+    l_clf = O.cross_entropy(O.speaker_classifier_forward(csd, logits, m['ns'], 0.0, 128, training=True), c)
+    (l_rec - alpha * l_clf).backward()
+    xd = x_bct.permute(0, 2, 1).contiguous().to(dev)
+    lr_, lc_, corr = cs.g_step(xd, c.to(dev), alpha, noise=G.contiguous().to(dev), noise_kind=0, update=False)
+    torch.cuda.synchronize()
+    assert abs(lr_.item() - l_rec.item()) < 1e-5 and abs(lc_.item() - l_clf.item()) < 1e-4
+    for net, ref in ((enc, esd), (dec, dsd)):
+        for k, g in _grad_dict(net).items():
+            r = ref[k].grad if ref[k].grad is not None else torch.zeros_like(ref[k])
+            scale = r.abs().max().item()
+            if scale < 1e-6:
+                continue
+            assert (g - r).abs().max().item() / scale < 3e-3, k
+    # D step: classifier gradients only
+    lc2, _ = cs.d_step(xd, c.to(dev), alpha_dis=1.0, noise=G.contiguous().to(dev), noise_kind=0, update=False)
+    torch.cuda.synchronize()
+    csd2 = {k: v.detach().clone().requires_grad_(True) for k, v in csd.items()}
+    with torch.no_grad():
+        _, lg = O.encoder_forward({k: v.detach() for k, v in esd.items()}, x_bct, m['ns'], 0.0, m['enc_size'], 128, G=G, training=True)
+    l2 = O.cross_entropy(O.speaker_classifier_forward(csd2, lg, m['ns'], 0.0, 128, training=True), c)
+    l2.backward()
+    assert abs(lc2.item() - l2.item()) < 1e-4
+    for k, g in _grad_dict(clf).items():
+        r = csd2[k].grad
+        scale = r.abs().max().item()
+        if scale < 1e-6:
+            continue
+        assert (g - r).abs().max().item() / scale < 3e-3, k
+    cs.optimizer_step()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p).all() for p in clf.parameters())

@@ -110,7 +110,7 @@ class EncoderEngine(object):
         L.call('zs_mbv_fwd', 'ZsMbvFwd', st, dtype=c.dt, logits=logits.ptr(), ld=logits.ld, logits_f32=1,
                noise=L.ptr(noise), noise_kind=noise_kind, seed=seed, rows=B * T4, E=E, tau=0.1, bits=bits.ptr(),
                ld_bits=bits.ld, bits_fill_cols=bits.ld, bits_f32=L.ptr(bits_f32), y0=L.ptr(y0))               # :476-480
-        tp.update(cat2=cat2, gates=gates, y0=y0, T4=T4, gru_in=a)
+        tp.update(cat2=cat2, gates=gates, y0=y0, T4=T4, gru_in=a, logits=logits)
         self.tape = tp
         return bits, bits_f32[:B * T4 * E].view(B, T4, E), logits
 
@@ -139,8 +139,9 @@ class EncoderEngine(object):
                seed=tp['seed'], stream_id=k + 1, mask=L.ptr(m), mask_ld=(m.shape[-1] if m is not None else 0), slope=self.ns)
 
     # ------------------------------------------------------------------------------------------
-    def backward(self, dbits):
-        """dbits: Act [B,T',E] gradient w.r.t. enc_act.  Fills every encoder parameter gradient (overwrite)."""
+    def backward(self, dbits, dlogits_extra=None):
+        """dbits: Act [B,T',E] gradient w.r.t. enc_act (may be None); dlogits_extra: Act [B,T',2E] gradient w.r.t. the
+        pre-activation `enc` (speaker-classifier term of trainer.py:444).  Fills every encoder parameter gradient."""
         c, ns, tp = self.ctx, self.ns, self.tape
         assert tp is not None and tp['training']
         B, T, Ts, T4 = tp['B'], tp['T'], tp['Ts'], tp['T4']
@@ -149,8 +150,13 @@ class EncoderEngine(object):
         tag = '_%d_%d_%d' % (self.uid, B, T)
         cat2 = tp['cat2']
         dlog = c.act('e_dlog' + tag, B, T4, 2 * E)
-        L.call('zs_mbv_bwd', 'ZsMbvBwd', st, dtype=c.dt, dbits=dbits.ptr(), ld_dbits=dbits.ld, y0=L.ptr(tp['y0']),
-               rows=B * T4, E=E, tau=0.1, dlogits=dlog.ptr(), ld=dlog.ld, fill_cols=dlog.ld)
+        if dbits is not None:
+            L.call('zs_mbv_bwd', 'ZsMbvBwd', st, dtype=c.dt, dbits=dbits.ptr(), ld_dbits=dbits.ld, y0=L.ptr(tp['y0']),
+                   rows=B * T4, E=E, tau=0.1, dlogits=dlog.ptr(), ld=dlog.ld, fill_cols=dlog.ld)
+            if dlogits_extra is not None:
+                dlog.t[:B * T4 * dlog.ld].add_(dlogits_extra.t[:B * T4 * dlogits_extra.ld])
+        else:
+            dlog = dlogits_extra
         self.linear.wgrad(dlog, cat2)
         dcat2 = c.act('e_dcat2' + tag, B, T4, cat2.C)
         self.linear.dgrad(dlog, T4, dcat2)
@@ -378,3 +384,106 @@ class DecoderEngine(object):
             dbits = c.act('d_dbits' + tag, B, T0, self.E)
             self.input_emb.dgrad(dx, T0, dbits)
         return dbits
+
+
+class ClassifierEngine(object):
+    """SpeakerClassifier.forward (reference model/model.py:262-280) and its backward: four conv blocks on the
+    T' = T/8 code sequence (conv k5/k3 + lrelu, InstanceNorm, Dropout, identity residual on blocks 2 and 3) and a
+    final un-padded Conv1d whose kernel spans the whole sequence (k = seg_len/8) -> logits [B, n_class]."""
+
+    def __init__(self, ctx, P, G, c_in, c_h, n_class, dp, ns, seg_len):
+        self.ctx, self.uid = ctx, _uid()
+        self.c_in, self.c_h, self.n_class = c_in, c_h, n_class
+        self.ns, self.dp = float(ns), float(dp)
+        self.pad_mode = L.ZS_PAD_REFLECT if seg_len >= 64 else L.ZS_PAD_ZERO
+        mk = lambda n, **kw: ConvLayer(ctx, P[n + '.weight'], P[n + '.bias'], G[n + '.weight'], G[n + '.bias'],
+                                       pad_mode=self.pad_mode, name=n, **kw)
+        self.blocks = [(mk('conv1'), mk('conv2'), False), (mk('conv3'), mk('conv4'), True), (mk('conv5'), mk('conv6'), True),
+                       (mk('conv7'), mk('conv8'), False)]
+        self.conv9 = mk('conv9', padded=False)
+        self.layers = [l for b in self.blocks for l in b[:2]] + [self.conv9]
+        self.tape = None
+
+    def pack(self):
+        for l in self.layers:
+            l.pack()
+
+    def forward(self, x, training, seed=0, drop_masks=None):
+        """x: Act [B, T', c_in] in the compute dtype.  Returns logits Act fp32 [B, 1, n_class]."""
+        c, ns = self.ctx, self.ns
+        B, T = x.B, x.T
+        if T != self.conv9.k:
+            raise L.ZsError('SpeakerClassifier expects %d encoded frames (got %d)' % (self.conv9.k, T))
+        tag = '_%d_%d_%d' % (self.uid, B, T)
+        dp = self.dp if training else 0.0
+        masks = drop_masks if drop_masks is not None else [None] * 4
+        tp = {'B': B, 'T': T, 'training': training, 'seed': seed, 'masks': masks, 'dp': dp, 'x': x, 'blocks': []}
+        a = x
+        for i, (la, lb, res) in enumerate(self.blocks):
+            ya = c.act('c_ya%d' % i + tag, B, T, la.Cout)
+            la.fwd(a, out=ya, act=LRELU, slope=ns)
+            yb = c.act('c_yb%d' % i + tag, B, T, lb.Cout)
+            lb.fwd(ya, out=yb, act=LRELU, slope=ns)
+            out = c.act('c_o%d' % i + tag, B, T, lb.Cout)
+            C = yb.ld
+            mean = rstd = None
+            if training:
+                mean, rstd = c.f32('c_mean%d' % i + tag, B * C), c.f32('c_rstd%d' % i + tag, B * C)
+            m = masks[i]
+            L.call('zs_instnorm_fwd', 'ZsInstNormFwd', c.stream, dtype=c.dt, x=yb.ptr(), ldx=yb.ld, out=out.ptr(), ldo=out.ld,
+                   mean=L.ptr(mean), rstd=L.ptr(rstd), B=B, T=T, C=C, eps=EPS_IN, drop_p=dp, seed=seed, stream_id=20 + i,
+                   mask=L.ptr(m), mask_ld=(m.shape[-1] if m is not None else 0),
+                   res_mode=(L.ZS_RES_IDENTITY if res else L.ZS_RES_NONE), res=(a.ptr() if res else None),
+                   ldres=(a.ld if res else 0), T_res=(T if res else 0), res_pad_mode=self.pad_mode)
+            tp['blocks'].append((a, ya, yb, (mean, rstd, i), res))
+            a = out
+        logits = c.act('c_logits' + tag, B, 1, self.n_class, dtype=torch.float32)
+        self.conv9.fwd(a, out=logits, out_f32=True)
+        tp['last'] = a
+        self.tape = tp
+        return logits
+
+    def backward(self, dlogits_f32, ld, need_dx=True, param_grads=True):
+        """dlogits_f32: fp32 tensor [B, ld] (from zs_softmax_ce).  Returns dx Act [B, T', c_in] (or None)."""
+        c, ns, tp = self.ctx, self.ns, self.tape
+        B, T = tp['B'], tp['T']
+        tag = '_%d_%d_%d' % (self.uid, B, T)
+        dl = c.act('c_dl' + tag, B, 1, self.n_class)
+        L.call('zs_cast_rows', 'ZsCastRows', c.stream, dtype=c.dt, src=L.ptr(dlogits_f32), ld_src=ld, src_f32=1, dst=dl.ptr(),
+               ld_dst=dl.ld, dst_f32=0, col_off=0, rows=B, cols=self.n_class, fill_cols=dl.ld, act=L.ZS_ACT_NONE)
+        if param_grads:
+            self.conv9.wgrad(dl, tp['last'])
+        da = c.act('c_da_last' + tag, B, T, self.conv9.Cin)
+        self.conv9.dgrad(dl, T, da)
+        for i in (3, 2, 1, 0):
+            la, lb, _ = self.blocks[i]
+            a, ya, yb, stt, res = tp['blocks'][i]
+            mean, rstd, k = stt
+            m = tp['masks'][k]
+            dzb = c.act('c_dzb%d' % i + tag, B, T, lb.Cout)
+            L.call('zs_instnorm_bwd', 'ZsInstNormBwd', c.stream, dtype=c.dt, dout=da.ptr(), ldd=da.ld, x=yb.ptr(), ldx=yb.ld,
+                   mean=L.ptr(mean), rstd=L.ptr(rstd), dz=dzb.ptr(), ldz=dzb.ld, B=B, T=T, C=yb.ld, drop_p=tp['dp'], seed=tp['seed'],
+                   stream_id=20 + k, mask=L.ptr(m), mask_ld=(m.shape[-1] if m is not None else 0), slope=ns)
+            if param_grads:
+                lb.wgrad(dzb, ya)
+            gp = c.act('c_gp%d' % i + tag, B, T + lb.pad_l + lb.pad_r, lb.Cin)
+            lb.dgrad(dzb, T, gp)
+            dza = c.act('c_dza%d' % i + tag, B, T, la.Cout)
+            self._combine(gp, T, lb.pad_l, lb.pad_r, dza, dact=ya)
+            if param_grads:
+                la.wgrad(dza, a)
+            if i == 0 and not need_dx:
+                return None
+            gp2 = c.act('c_gq%d' % i + tag, B, T + la.pad_l + la.pad_r, la.Cin)
+            la.dgrad(dza, T, gp2)
+            dn = c.act('c_da%d' % i + tag, B, T, la.Cin)
+            self._combine(gp2, T, la.pad_l, la.pad_r, dn, res_mode=(L.ZS_RES_IDENTITY if res else L.ZS_RES_NONE), res=(da if res else None))
+            da = dn
+        return da
+
+    def _combine(self, gp, T, pl, pr, out, res_mode=L.ZS_RES_NONE, res=None, dact=None):
+        c = self.ctx
+        L.call('zs_grad_combine', 'ZsGradCombine', c.stream, dtype=c.dt, gp=gp.ptr(), ldg=gp.ld, pad_left=pl, pad_right=pr,
+               pad_mode=self.pad_mode, B=gp.B, T=T, C=gp.ld, res_mode=res_mode, res=(res.ptr() if res is not None else None),
+               ldres=(res.ld if res is not None else 0), dact_src=(dact.ptr() if dact is not None else None),
+               dact_ld=(dact.ld if dact is not None else 0), slope=self.ns, out=out.ptr(), ldo=out.ld, unshuffle=0)

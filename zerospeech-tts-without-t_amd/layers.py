@@ -122,14 +122,14 @@ class ConvLayer(object):
     """Conv1d [Cout,Cin,k] or Linear [Cout,Cin] (k=1) as packed MFMA operands.
     split2: output channels packed so that the epilogue can pixel-shuffle (see zs_amd.h)."""
 
-    def __init__(self, ctx, weight, bias, gweight, gbias, stride=1, split2=False, pad_mode=L.ZS_PAD_REFLECT, name=''):
+    def __init__(self, ctx, weight, bias, gweight, gbias, stride=1, split2=False, pad_mode=L.ZS_PAD_REFLECT, name='', padded=True):
         self.ctx, self.name = ctx, name
         self.w, self.b, self.gw, self.gb = weight, bias, gweight, gbias
         self.Cout, self.Cin = weight.shape[0], weight.shape[1]
         self.k = weight.shape[2] if weight.dim() == 3 else 1
         self.stride, self.split2, self.pad_mode = stride, split2, pad_mode
-        self.pad_l = self.k // 2
-        self.pad_r = self.k - 1 - self.k // 2
+        self.pad_l = self.k // 2 if padded else 0              # pad_layer(): (k//2, k//2 - 1 | k//2); plain nn.Conv1d: none
+        self.pad_r = (self.k - 1 - self.k // 2) if padded else 0
         self.so, self.si, self.sj = (self.Cin * self.k, self.k, 1) if weight.dim() == 3 else (self.Cin, 1, 0)
         kc = ctx.kc                                       # elements per 128-byte K chunk
         self.cin_pad, self.cout_pad = rup(self.Cin, kc), rup(self.Cout, kc)

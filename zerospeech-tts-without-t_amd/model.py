@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .engine import DecoderEngine, EncoderEngine
+from .engine import ClassifierEngine, DecoderEngine, EncoderEngine
 from .layers import Act, Ctx, rup
 
 
@@ -196,3 +196,53 @@ class Decoder(ZsModule):
         cidx = c.detach().to(xb.device, torch.int64).contiguous()
         xdec = eng.forward(bits, cidx, self.training)
         return xdec.valid().permute(0, 2, 1).clone()
+
+
+class SpeakerClassifier(ZsModule):
+    """model/model.py:231-280."""
+
+    def __init__(self, c_in=512, c_h=512, n_class=8, dp=0.1, ns=0.01, seg_len=128, dtype=None):
+        super(SpeakerClassifier, self).__init__(dtype)
+        self.dp, self.ns, self.seg_len = dp, ns, seg_len
+        self.c_in, self.c_h, self.n_class = c_in, c_h, n_class
+        self.conv1 = nn.Conv1d(c_in, c_h, kernel_size=5)
+        self.conv2 = nn.Conv1d(c_h, c_h, kernel_size=5)
+        self.conv3 = nn.Conv1d(c_h, c_h, kernel_size=5)
+        self.conv4 = nn.Conv1d(c_h, c_h, kernel_size=5)
+        self.conv5 = nn.Conv1d(c_h, c_h, kernel_size=5)
+        self.conv6 = nn.Conv1d(c_h, c_h, kernel_size=5)
+        self.conv7 = nn.Conv1d(c_h, c_h // 2, kernel_size=3)
+        self.conv8 = nn.Conv1d(c_h // 2, c_h // 4, kernel_size=3)
+        if seg_len == 128:
+            self.conv9 = nn.Conv1d(c_h // 4, n_class, kernel_size=16)
+        elif seg_len == 64:
+            self.conv9 = nn.Conv1d(c_h // 4, n_class, kernel_size=8)
+        elif seg_len == 32:
+            self.conv9 = nn.Conv1d(c_h // 4, n_class, kernel_size=4)
+        else:
+            raise NotImplementedError('Segement length {} is not supported!'.format(seg_len))
+
+    def _make_engine(self, ctx, P, G):
+        return ClassifierEngine(ctx, P, G, self.c_in, self.c_h, self.n_class, self.dp, self.ns, self.seg_len)
+
+    def input_act(self, x_btc_f32):
+        """fp32 [B, T', c_in] (contiguous, on the device) -> Act in the compute dtype."""
+        eng = self._engine()
+        ctx = eng.ctx
+        B, T, C = x_btc_f32.shape
+        a = ctx.act('c_in_%d_%d_%d' % (eng.uid, B, T), B, T, C)
+        L.call('zs_cast_rows', 'ZsCastRows', ctx.stream, dtype=ctx.dt, src=L.ptr(x_btc_f32), ld_src=x_btc_f32.stride(1), src_f32=1,
+               dst=a.ptr(), ld_dst=a.ld, dst_f32=0, col_off=0, rows=B * T, cols=C, fill_cols=a.ld, act=L.ZS_ACT_NONE)
+        return a
+
+    def forward(self, x, drop_masks=None, seed=None):
+        """x: enc [B, c_in, T'] -> logits [B, n_class]."""
+        eng = self._engine()
+        xb = x.detach().permute(0, 2, 1).contiguous().float()
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        masks = None
+        if drop_masks is not None:
+            masks = [m.to(xb.device, torch.uint8).contiguous() if m is not None else None for m in drop_masks]
+        logits = eng.forward(self.input_act(xb), self.training, seed=seed, drop_masks=masks)
+        return logits.valid()[:, 0, :].clone()

@@ -18,7 +18,7 @@ import torch
 from . import _lib as L
 from . import parallel
 from .layers import Act, join_side
-from .model import Decoder, Encoder
+from .model import Decoder, Encoder, SpeakerClassifier
 from .utils import Logger
 
 
@@ -103,6 +103,103 @@ class AEStep(object):
             net.mark_dirty()
 
 
+class ClfStep(object):
+    """Speaker-classifier side of stage 1 (trainer.py:349-465): the D step trains SpeakerClassifier on the encoder's
+    pre-activation `enc` (CE, per-net clip, Adam betas (0.5, 0.9)); the G step trains Encoder+Decoder with
+    loss_rec - alpha * loss_clf (the classifier only passes the gradient through)."""
+
+    def __init__(self, ae, classifier, lr=1e-4, betas=(0.5, 0.9), max_grad_norm=5.0):
+        self.ae, self.clf = ae, classifier
+        self.lr, self.betas, self.max_grad_norm = float(lr), betas, float(max_grad_norm)
+        self.adam_step = 0
+        dev = ae.device
+        self.device = dev
+        flat, _ = classifier.flat_params()
+        self.m, self.v = torch.zeros_like(flat), torch.zeros_like(flat)
+        self.sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.part = torch.zeros(1024, dtype=torch.float64, device=dev)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.correct = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._dl = None
+
+    def _classify(self, logits_act, c, grad_scale, seed, drop_masks=None):
+        """enc logits Act fp32 [B,T',2E] -> CE loss (device scalar), fills self._dl = grad_scale * dCE/dlogits."""
+        clf = self.clf
+        clf.train()
+        ce = clf._engine()
+        B, T = logits_act.B, logits_act.T
+        x = clf.input_act(logits_act.valid())
+        out = ce.forward(x, True, seed=seed, drop_masks=drop_masks)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        if self._dl is None or self._dl.shape != (B, out.ld):
+            self._dl = torch.zeros(B, out.ld, dtype=torch.float32, device=self.device)
+        L.call('zs_softmax_ce', 'ZsSoftmaxCE', st, logits=out.ptr(), ld=out.ld, target=L.ptr(c), B=B, n_class=clf.n_class,
+               loss_out=L.ptr(self.loss), dlogits=L.ptr(self._dl), ldg=out.ld, grad_scale=float(grad_scale),
+               correct_out=L.ptr(self.correct))                                              # cal_loss / cal_acc, trainer.py:297-313
+        return ce, out
+
+    def d_step(self, x_btf, c, alpha_dis=1.0, seed=None, update=True, noise=None, noise_kind=2, drop_masks=None, clf_masks=None):
+        """One classifier update (trainer.py:352-366 / 396-411).  Returns (loss_clf, n_correct) device scalars."""
+        enc = self.ae.Encoder
+        enc.train()
+        ee = enc._engine()
+        if seed is None:
+            seed = (self.adam_step + 1) * 0x9E3779B97F4A7C15 % (1 << 62) + 17 * parallel.rank()
+        _, _, logits = ee.forward(x_btf, True, noise=noise, noise_kind=noise_kind, seed=seed, drop_masks=drop_masks)
+        ce, out = self._classify(logits, c, alpha_dis, seed + 1, clf_masks)
+        ce.backward(self._dl, out.ld, need_dx=False)
+        join_side(self.device)
+        if update:
+            self.optimizer_step()
+        return self.loss, self.correct
+
+    def optimizer_step(self):
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        flat, gflat = self.clf.flat_params()
+        L.check(L.lib().zs_sqnorm(L.ptr(gflat), gflat.numel(), L.ptr(self.part), L.ptr(self.sq), st), 'zs_sqnorm')
+        self.adam_step += 1
+        b1, b2 = self.betas
+        L.call('zs_adam_clip', 'ZsAdam', st, p=L.ptr(flat), g=L.ptr(gflat), m=L.ptr(self.m), v=L.ptr(self.v), n=flat.numel(),
+               lr=self.lr, beta1=b1, beta2=b2, eps=1e-8, bc1=1.0 - b1 ** self.adam_step, bc2=1.0 - b2 ** self.adam_step,
+               sumsq=L.ptr(self.sq), max_norm=self.max_grad_norm, write_clipped_grad=0)
+        self.clf.mark_dirty()
+
+    def g_step(self, x_btf, c, alpha, seed=None, update=True, noise=None, noise_kind=2, drop_masks=None, clf_masks=None):
+        """One autoencoder update with the adversarial term (trainer.py:427-447): loss = loss_rec - alpha * loss_clf.
+        Returns (loss_rec, loss_clf, n_correct) device scalars."""
+        ae = self.ae
+        enc, dec = ae.Encoder, ae.Decoder
+        enc.train(); dec.train()
+        ee, de = enc._engine(), dec._engine()
+        ctx = ee.ctx
+        st = ctx.stream
+        B, T, F = x_btf.shape
+        if seed is None:
+            seed = (ae.adam_step + 1) * 0x9E3779B97F4A7C15 % (1 << 62) + 31 * parallel.rank()
+        bits, _, logits = ee.forward(x_btf, True, noise=noise, noise_kind=noise_kind, seed=seed, drop_masks=drop_masks)
+        xdec = de.forward(bits, c, True)
+        dlogit = de.ctx.act('t_dlogit_%d_%d' % (B, T), B, xdec.T, F)
+        L.call('zs_l1_loss', 'ZsL1Loss', st, dtype=ctx.dt, x_dec=xdec.ptr(), ld_dec=xdec.ld, x=L.ptr(x_btf), ldx=F,
+               rows=B * xdec.T, F=F, dlogits=dlogit.ptr(), ldg=dlogit.ld, fill_cols=dlogit.ld, partial=L.ptr(ae._lpart),
+               loss_out=L.ptr(ae._loss), grad_scale=1.0)
+        ce, out = self._classify(logits, c, -float(alpha), seed + 1, clf_masks)          # maximise the classification loss
+        dbits = de.backward(dlogit)
+        dx = ce.backward(self._dl, out.ld, need_dx=True, param_grads=False)
+        multi = parallel.world_size() > 1
+        if multi:
+            join_side(self.device)
+            ae.reducer.start(dec.flat_params()[1])
+        ee.backward(dbits, dlogits_extra=dx)
+        join_side(self.device)
+        if multi:
+            ae.reducer.start(enc.flat_params()[1])
+            ae.reducer.finish()
+        ae.xdec = xdec
+        if update:
+            ae.optimizer_step()
+        return ae._loss, self.loss, self.correct
+
+
 class Trainer(object):
     def __init__(self, hps, data_loader, g_mode, enc_mode, log_dir='./log/', dtype=None, device=None):
         self.hps = hps
@@ -139,7 +236,13 @@ class Trainer(object):
             raise NotImplementedError('g_mode %r (stage-2 generator) is outside the MI355X hot path' % self.g_mode)
         else:
             raise NotImplementedError('Invalid Generator mode!')
+        enc_size = hps.enc_size
+        self.SpeakerClassifier = SpeakerClassifier(ns=ns, c_in=(enc_size * enc_size if self.enc_mode == 'binary' else
+                                                                (2 * enc_size if self.enc_mode == 'multilabel_binary' else enc_size)),
+                                                   c_h=hps.emb_size, n_class=hps.n_speakers, dp=hps.dis_dp, seg_len=hps.seg_len,
+                                                   dtype=dt).to(dev)
         self.ae = AEStep(self.Encoder, self.Decoder, lr=hps.lr, betas=(0.5, 0.9), max_grad_norm=hps.max_grad_norm)
+        self.clf = ClfStep(self.ae, self.SpeakerClassifier, lr=hps.lr, betas=(0.5, 0.9), max_grad_norm=hps.max_grad_norm)
         self.testing_shift_c = None
 
     def reset_keep(self):
@@ -151,6 +254,7 @@ class Trainer(object):
             'encoder': self.Encoder.state_dict(),
             'decoder': self.Decoder.state_dict(),
             'generator': self.Generator.state_dict(),
+            'classifier': self.SpeakerClassifier.state_dict(),
         }
         all_model = {k: {n: t.detach().cpu().clone() for n, t in sd.items()} for k, sd in all_model.items()}
         new_model_path = '{}-{}-{}'.format(model_path, name, iteration)
@@ -168,7 +272,7 @@ class Trainer(object):
         if verbose:
             print('[Trainer] - ', end='')
         for key, net, tag in (('encoder', self.Encoder, 'encoder'), ('decoder', self.Decoder, 'decoder'),
-                              ('generator', self.Generator, 'generator')):
+                              ('generator', self.Generator, 'generator'), ('classifier', self.SpeakerClassifier, 'classifier')):
             if key in load_model_list:
                 try:
                     net.load_state_dict(all_model[key])
@@ -184,6 +288,7 @@ class Trainer(object):
         self.testing_shift_c = torch.tensor([int(self.hps.n_speakers - self.hps.n_target_speakers)], device=self.device)
         self.Encoder.eval()
         self.Decoder.eval()
+        self.SpeakerClassifier.eval()
         self.Generator.eval()
 
     def test_step(self, x, c, enc_only=False, verbose=True, U=None, G=None):
@@ -227,31 +332,86 @@ class Trainer(object):
     def decode_step(self, enc, c):
         return self.Decoder(enc, c)
 
+    def clf_step(self, enc):
+        return self.SpeakerClassifier(enc)
+
     def ae_step(self, x_btf, c, **kw):
         """One fused --train_ae iteration; see AEStep.step."""
         return self.ae.step(x_btf, c, **kw)
 
     # ---- the loop (trainer.py:316-347) -----------------------------------------------------------
+    def _batch(self):
+        data = next(self.data_loader)
+        c = data[0].to(self.device, non_blocking=True)
+        x = data[1].to(self.device, non_blocking=True).float().contiguous()              # [B, seg_len, 513]
+        return c, x
+
     def train(self, model_path, flag='train', mode='train', target_guided=False):
         hps = self.hps
-        if mode != 'pretrain_AE':
-            raise NotImplementedError("mode %r is outside the MI355X hot path this build covers ('pretrain_AE' = --train_ae)" % mode)
         is_main = parallel.rank() == 0
-        for iteration in range(hps.enc_pretrain_iters):
-            data = next(self.data_loader)
-            c = data[0].to(self.device, non_blocking=True)
-            x = data[1].to(self.device, non_blocking=True).float().contiguous()          # [B, seg_len, 513]
-            loss_t = self.ae_step(x, c)
-            if (iteration % self.log_every == 0) or (iteration + 1 == hps.enc_pretrain_iters):
-                loss_rec = loss_t.item()                                                  # the only host sync
-                info = {f'{flag}/pre_loss_rec': loss_rec}
-                slot_value = (iteration + 1, hps.enc_pretrain_iters) + tuple(info.values())
-                if is_main:
-                    print('pre_AE:[%06d/%06d], loss_rec=%.3f' % slot_value, end='\r')
+        if mode == 'pretrain_AE':                                                         # trainer.py:320-347
+            for iteration in range(hps.enc_pretrain_iters):
+                c, x = self._batch()
+                loss_t = self.ae_step(x, c)
+                if (iteration % self.log_every == 0) or (iteration + 1 == hps.enc_pretrain_iters):
+                    loss_rec = loss_t.item()                                              # the only host sync
+                    info = {f'{flag}/pre_loss_rec': loss_rec}
+                    slot_value = (iteration + 1, hps.enc_pretrain_iters) + tuple(info.values())
+                    if is_main:
+                        print('pre_AE:[%06d/%06d], loss_rec=%.3f' % slot_value, end='\r')
+                        if iteration % 100 == 0:
+                            for tag, value in info.items():
+                                self.logger.scalar_summary(tag, value, iteration + 1)
+                if (iteration + 1) % 1000 == 0 and is_main:
+                    self.save_model(model_path, 'ae', iteration + 1)
+            if is_main:
+                print()
+        elif mode == 'pretrain_C':                                                        # trainer.py:349-382
+            for iteration in range(hps.dis_pretrain_iters):
+                c, x = self._batch()
+                loss_t, corr = self.clf.d_step(x, c)
+                if (iteration % self.log_every == 0) or (iteration + 1 == hps.dis_pretrain_iters):
+                    info = {f'{flag}/pre_loss_clf': loss_t.item(), f'{flag}/pre_acc': corr.item() / float(c.shape[0])}
+                    slot_value = (iteration + 1, hps.dis_pretrain_iters) + tuple(info.values())
+                    if is_main:
+                        print('pre_C:[%06d/%06d], loss_clf=%.2f, acc=%.2f' % slot_value, end='\r')
+                        if iteration % 100 == 0:
+                            for tag, value in info.items():
+                                self.logger.scalar_summary(tag, value, iteration + 1)
+                if (iteration + 1) % 1000 == 0 and is_main:
+                    self.save_model(model_path, 'c', iteration + 1)
+            if is_main:
+                print()
+        elif mode == 'train':                                                             # trainer.py:384-465
+            for iteration in range(hps.iters):
+                if iteration < hps.lat_sched_iters:
+                    current_alpha = hps.alpha_enc * (iteration / hps.lat_sched_iters)
+                else:
+                    current_alpha = hps.alpha_enc
+                log_now = (iteration % self.log_every == 0) or (iteration + 1 == hps.iters)
+                for step in range(hps.n_latent_steps):                                    # train D
+                    c, x = self._batch()
+                    loss_t, corr = self.clf.d_step(x, c, alpha_dis=hps.alpha_dis)
+                    if log_now and is_main:
+                        info = {f'{flag}/D_loss_clf': loss_t.item(),
+                                f'{flag}/D_acc': corr.item() / float(c.shape[0])}
+                        print('D-%d:[%06d/%06d], loss_clf=%.2f, acc=%.2f' % ((step, iteration + 1, hps.iters) + tuple(info.values())), end='\r')
+                        if iteration % 100 == 0:
+                            for tag, value in info.items():
+                                self.logger.scalar_summary(tag, value, iteration + 1)
+                c, x = self._batch()                                                      # train G
+                l_rec, l_clf, corr = self.clf.g_step(x, c, current_alpha)
+                if log_now and is_main:
+                    info = {f'{flag}/loss_rec': l_rec.item(), f'{flag}/G_loss_clf': l_clf.item(), f'{flag}/alpha': current_alpha,
+                            f'{flag}/G_acc': corr.item() / float(c.shape[0])}
+                    print('G:[%06d/%06d], loss_rec=%.3f, loss_clf=%.2f, alpha=%.2e, acc=%.2f' % ((iteration + 1, hps.iters) + tuple(info.values())),
+                          end='\r')
                     if iteration % 100 == 0:
                         for tag, value in info.items():
                             self.logger.scalar_summary(tag, value, iteration + 1)
-            if (iteration + 1) % 1000 == 0 and is_main:
-                self.save_model(model_path, 'ae', iteration + 1)
-        if is_main:
-            print()
+                if (iteration + 1) % 1000 == 0 and is_main:
+                    self.save_model(model_path, 's1', iteration + 1)
+            if is_main:
+                print()
+        else:
+            raise NotImplementedError("mode %r (stage 2 / Tacotron) is outside the MI355X hot path this build covers" % mode)
