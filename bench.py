@@ -186,13 +186,14 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
+    t_host = time.perf_counter() - t0                 # host time to ENQUEUE the steps (no synchronisation inside)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ke.enabled = False
-    log('timed %d steps: %.3f s' % (args.steps, dt))
+    log('timed %d steps: %.3f s (host enqueue %.3f s)' % (args.steps, dt, t_host))
     loss = float(ae._loss.item())
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -209,7 +210,7 @@ def main():
         'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': 'train_ae english hps seg_len=128 enc_size=1024 emb_size=1024 n_speakers=102 F=513, batch=%d/GPU, '
                                'dropout+Gumbel on, fwd+bwd+clip+Adam' % B, 'global_batch': B * world, 'parallelism': 'dp%d' % world},
-        'final_loss': loss, 'host_input': bool(args.host_input),
+        'final_loss': loss, 'host_input': bool(args.host_input), 'host_enqueue_ms_per_step': 1e3 * t_host / args.steps,
     }
     peak = 2500.0 if args.dtype == 'bf16' else 157.3
     traffic = None

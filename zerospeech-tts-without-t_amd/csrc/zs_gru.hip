@@ -114,7 +114,8 @@ struct RowGemmArgs {
   const void* W; int64_t ldw; int64_t w_gstride;
   int M, N, K;
   float* out; int64_t out_gstride;     // plain mode: fp32 [g][M][N]
-  GateFwdArgs gate;                    // GRU mode
+  GateFwdArgs gate;                    // MODE 1: fused forward gates
+  GateBwdArgs gbw;                     // MODE 2: fused backward gates of the NEXT BPTT step
 };
 
 template <typename T> struct Frag16;
@@ -136,8 +137,9 @@ template <> struct Frag16<float> {
 
 constexpr int RB = 2;                                  // 16-row blocks per workgroup (32 rows): W is re-read B/32 times per step
 
-template <typename T, int NT16, bool GRU>
+template <typename T, int NT16, int MODE>   // MODE 0 plain fp32 out, 1 GRU forward gates, 2 GRU backward gates (next step)
 __global__ __launch_bounds__(256) void rowblock_gemm_kernel(const RowGemmArgs a) {
+  constexpr bool GRU = (MODE == 1);
   // workgroup = one (16*RB)-row x (16*NT16)-column tile; its 4 waves split K and reduce through LDS
   constexpr int KSTEP = Frag16<T>::KSTEP;
   constexpr int EPL = 16 / (int)sizeof(T);            // elements per lane per fragment
@@ -171,6 +173,31 @@ __global__ __launch_bounds__(256) void rowblock_gemm_kernel(const RowGemmArgs a)
         const T* gi = (const T*)ga.gi + ((int64_t)b * ga.T + e_t) * ga.ldgi + (int64_t)d * 3 * H;
         e_gi[pz][0] = Elem<T>::ld(gi + j); e_gi[pz][1] = Elem<T>::ld(gi + H + j); e_gi[pz][2] = Elem<T>::ld(gi + 2 * H + j);
         if (!skip) e_hp[pz] = ga.hstate[((int64_t)d * ga.B + b) * H + j];
+      }
+    }
+  }
+
+  // ---- MODE 2: operands of the next BPTT step's gate math (same (row, unit) ownership), loaded up front ----
+  float w_r[NP], w_z[NP], w_n[NP], w_hn[NP], w_dh[NP], w_hp[NP];
+  int w_t = 0;
+  if constexpr (MODE == 2) {
+    static_assert(NT16 == 2 || MODE != 2, "fused backward gates need a 32-column tile");
+    const GateBwdArgs& gb = a.gbw;
+    const int d = g, H = gb.H, j = blockIdx.x * 32 + eu;
+    w_t = d == 0 ? gb.T - 1 - gb.step : gb.step;              // time index of BPTT step gb.step
+#pragma unroll
+    for (int pz = 0; pz < NP; ++pz) {
+      w_r[pz] = w_z[pz] = w_n[pz] = w_hn[pz] = w_dh[pz] = w_hp[pz] = 0.f;
+      const int b = m0 + e_row + 8 * pz;
+      if (b < a.M) {
+        const int64_t row = (int64_t)b * gb.T + w_t;
+        const T* gs = (const T*)gb.gates + (row * 2 + d) * 4 * H;
+        w_r[pz] = Elem<T>::ld(gs + j); w_z[pz] = Elem<T>::ld(gs + H + j); w_n[pz] = Elem<T>::ld(gs + 2 * H + j); w_hn[pz] = Elem<T>::ld(gs + 3 * H + j);
+        w_dh[pz] = Elem<T>::ld((const T*)gb.dout + row * gb.ldd + gb.dout_col + d * H + j) + gb.dhd[((int64_t)d * gb.B + b) * H + j];
+        if (gb.step < gb.T - 1) {
+          const int tp = d == 0 ? w_t - 1 : w_t + 1;
+          w_hp[pz] = Elem<T>::ld((const T*)gb.out + ((int64_t)b * gb.T + tp) * gb.ldo + gb.out_col + d * H + j);
+        }
       }
     }
   }
@@ -239,7 +266,31 @@ __global__ __launch_bounds__(256) void rowblock_gemm_kernel(const RowGemmArgs a)
     const int rb = rr >> 4, l = ((rr & 15) >> 2) * 16 + cc, i = rr & 3;
     return (part[0][rb][c][i][l] + part[1][rb][c][i][l]) + (part[2][rb][c][i][l] + part[3][rb][c][i][l]);
   };
-  if constexpr (!GRU) {
+  if constexpr (MODE == 2) {
+    // dh_{s+1} = dout + dh_s*z_s (dhd) + dgh_s W_hh (this product); gate backward of step s+1 for the owned (row, unit)
+    const GateBwdArgs& gb = a.gbw;
+    const int d = g, H = gb.H, j = blockIdx.x * 32 + eu;
+    const int hh = eu >> 4, cc = eu & 15;
+#pragma unroll
+    for (int pz = 0; pz < NP; ++pz) {
+      const int rr = e_row + 8 * pz;
+      const int b = m0 + rr;
+      if (b >= a.M) continue;
+      const float dh = w_dh[pz] + total(hh, rr, cc);
+      const float r_ = w_r[pz], z_ = w_z[pz], n_ = w_n[pz];
+      const float dn = dh * (1.f - z_);
+      const float dz = dh * (w_hp[pz] - n_);
+      gb.dhd[((int64_t)d * gb.B + b) * H + j] = dh * z_;
+      const float dn_pre = dn * (1.f - n_ * n_);
+      const float dr_pre = dn_pre * w_hn[pz] * r_ * (1.f - r_);
+      const float dz_pre = dz * z_ * (1.f - z_);
+      const int64_t row = (int64_t)b * gb.T + w_t;
+      T* gi = (T*)gb.dgi + row * gb.ldgi + (int64_t)d * 3 * H;
+      T* gh = (T*)gb.dgh + row * gb.ldgh + (int64_t)d * 3 * H;
+      Elem<T>::st(gi + j, dr_pre); Elem<T>::st(gi + H + j, dz_pre); Elem<T>::st(gi + 2 * H + j, dn_pre);
+      Elem<T>::st(gh + j, dr_pre); Elem<T>::st(gh + H + j, dz_pre); Elem<T>::st(gh + 2 * H + j, dn_pre * r_);
+    }
+  } else if constexpr (!GRU) {
     float* out = a.out + (int64_t)g * a.out_gstride;
     constexpr int NC = 16 * NT16;
     for (int e = tid; e < ROWS * NC; e += 256) {        // coalesced along the columns
@@ -312,8 +363,8 @@ extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
       g.gi = p->gi; g.ldgi = p->ldgi; g.gh = nullptr; g.bhh = p->bhh; g.bhh_gstride = p->bhh_gstride; g.hstate = hstate;
       g.out = p->out; g.ldo = p->ldo; g.out_col = p->out_col; g.gates = p->gates; g.B = B; g.T = T; g.H = H; g.step = s;
       dim3 grid(H / 32, (B + 16 * RB - 1) / (16 * RB), 2);
-      if (p->dtype == ZS_F32) hipLaunchKernelGGL((rowblock_gemm_kernel<float, 6, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
-      else hipLaunchKernelGGL((rowblock_gemm_kernel<bf16_t, 6, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      if (p->dtype == ZS_F32) hipLaunchKernelGGL((rowblock_gemm_kernel<float, 6, 1>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((rowblock_gemm_kernel<bf16_t, 6, 1>), grid, dim3(256), 0, (hipStream_t)stream, a);
       int rc = zs_check_launch("zs_gru_fwd.step");
       if (rc) return rc;
     }
@@ -360,28 +411,33 @@ extern "C" int zs_gru_bwd(const ZsGruBwd* p, void* stream) {
   float* dhd = p->work + (size_t)2 * B * 3 * H;
   float* dhg = dhd + (size_t)2 * B * H;
   const char* dghb = (const char*)p->dgh;
+  const bool fast = (H % 32 == 0);
   for (int s = 0; s < T; ++s) {
     GateBwdArgs a;
     a.dout = p->dout; a.ldd = p->ldd; a.dout_col = p->dout_col; a.out = p->out; a.ldo = p->ldo; a.out_col = p->out_col;
     a.gates = p->gates; a.dhd = dhd; a.dhg = dhg; a.dgi = p->dgi; a.ldgi = p->ldgi; a.dgh = p->dgh; a.ldgh = p->ldgh;
     a.B = B; a.T = T; a.H = H; a.step = s;
-    const unsigned nb = gate_blocks((int64_t)2 * B * H);
-    if (p->dtype == ZS_F32) hipLaunchKernelGGL(gru_gate_bwd_kernel<float>, dim3(nb), dim3(NTG), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(gru_gate_bwd_kernel<bf16_t>, dim3(nb), dim3(NTG), 0, (hipStream_t)stream, a);
-    int rc = zs_check_launch("zs_gru_bwd.gate");
-    if (rc) return rc;
-    if (s < T - 1 && H % 32 == 0) {
-      RowGemmArgs a;
-      memset(&a, 0, sizeof(a));
+    int rc = ZS_OK;
+    if (s == 0 || !fast) {                       // fast path: steps >= 1 have their gate math fused into the product below
+      const unsigned nb = gate_blocks((int64_t)2 * B * H);
+      if (p->dtype == ZS_F32) hipLaunchKernelGGL(gru_gate_bwd_kernel<float>, dim3(nb), dim3(NTG), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL(gru_gate_bwd_kernel<bf16_t>, dim3(nb), dim3(NTG), 0, (hipStream_t)stream, a);
+      rc = zs_check_launch("zs_gru_bwd.gate");
+      if (rc) return rc;
+    }
+    if (s < T - 1 && fast) {
+      // dh carry of step s+1 = dgh_s W_hh (MFMA product) ; epilogue = gate backward of step s+1
+      RowGemmArgs ra;
+      memset(&ra, 0, sizeof(ra));
       const int64_t off0 = (int64_t)(T - 1 - s) * p->ldgh;
       const int64_t off1 = (int64_t)s * p->ldgh + 3 * H;
-      a.A = dghb + off0 * es; a.a_row_stride = (int64_t)T * p->ldgh; a.a_gstride = off1 - off0;
-      a.W = p->whh_t; a.ldw = p->ldw; a.w_gstride = p->w_gstride;
-      a.M = B; a.N = H; a.K = 3 * H;
-      a.out = dhg; a.out_gstride = (int64_t)B * H;
+      ra.A = dghb + off0 * es; ra.a_row_stride = (int64_t)T * p->ldgh; ra.a_gstride = off1 - off0;
+      ra.W = p->whh_t; ra.ldw = p->ldw; ra.w_gstride = p->w_gstride;
+      ra.M = B; ra.N = H; ra.K = 3 * H;
+      ra.gbw = a; ra.gbw.step = s + 1;
       dim3 grid(H / 32, (B + 16 * RB - 1) / (16 * RB), 2);
-      if (p->dtype == ZS_F32) hipLaunchKernelGGL((rowblock_gemm_kernel<float, 2, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
-      else hipLaunchKernelGGL((rowblock_gemm_kernel<bf16_t, 2, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      if (p->dtype == ZS_F32) hipLaunchKernelGGL((rowblock_gemm_kernel<float, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, ra);
+      else hipLaunchKernelGGL((rowblock_gemm_kernel<bf16_t, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, ra);
       rc = zs_check_launch("zs_gru_bwd.step");
       if (rc) return rc;
     } else if (s < T - 1) {
