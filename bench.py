@@ -36,6 +36,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='issue every launch from the host instead of replaying hipGraphs')
     ap.add_argument('--host-input', action='store_true', help='copy the batch from pinned host memory every step (PCIe-inclusive rate; never the headline value)')
     return ap.parse_args()
 
@@ -158,7 +159,7 @@ def main():
         for net in (enc, dec):
             dist.broadcast(net.flat_params()[0], src=0)
             net.mark_dirty()
-    ae = AEStep(enc, dec, lr=1e-4, max_grad_norm=5.0)
+    ae = AEStep(enc, dec, lr=1e-4, max_grad_norm=5.0, use_graph=not args.no_graph)
     g = torch.Generator().manual_seed(99 + rank)       # distinct per-rank data
     x = (torch.rand(B, seg_len, F, generator=g) * (1 - 1e-8) + 1e-8).to(dev)
     c = torch.randint(0, nspk, (B,), generator=g).to(dev)
@@ -173,7 +174,12 @@ def main():
     ke = KernelEvents()
     if not args.no_kernel_events:
         ke.install()
-    log('model built (%s, B=%d), warm-up' % (args.dtype, B))
+    log('model built (%s, B=%d, graph=%s)' % (args.dtype, B, ae.use_graph))
+    if ae.use_graph:                                   # set-up, not warm-up: 2 eager steps + the capture step
+        for _ in range(3):
+            one_step()
+        torch.cuda.synchronize()
+        log('hipGraph captured (%d graph segment(s))' % sum(len(v['graphs']) for v in ae._graphs.values()))
     for i in range(args.warmup):
         one_step()
         torch.cuda.synchronize()
@@ -182,7 +188,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ke.enabled = not args.no_kernel_events
+    ke.enabled = (not args.no_kernel_events) and not ae.use_graph
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
@@ -194,6 +200,17 @@ def main():
     dt = time.perf_counter() - t0
     ke.enabled = False
     log('timed %d steps: %.3f s (host enqueue %.3f s)' % (args.steps, dt, t_host))
+    if ae.use_graph and not args.no_kernel_events:
+        # HIP events cannot bracket kernels inside a replayed graph: the per-kernel durations for the roofline come from
+        # instrumented EAGER steps of the same workload, run right after the timed region in this process
+        ae.use_graph = False
+        ke.enabled = True
+        for _ in range(min(10, max(3, args.steps))):
+            one_step()
+        torch.cuda.synchronize()
+        ke.enabled = False
+        ae.use_graph = True
+        log('instrumented eager steps for the roofline: %d gemm_conv launches timed' % len(ke.pairs))
     loss = float(ae._loss.item())
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -210,7 +227,7 @@ def main():
         'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': 'train_ae english hps seg_len=128 enc_size=1024 emb_size=1024 n_speakers=102 F=513, batch=%d/GPU, '
                                'dropout+Gumbel on, fwd+bwd+clip+Adam' % B, 'global_batch': B * world, 'parallelism': 'dp%d' % world},
-        'final_loss': loss, 'host_input': bool(args.host_input), 'host_enqueue_ms_per_step': 1e3 * t_host / args.steps,
+        'final_loss': loss, 'host_input': bool(args.host_input), 'host_enqueue_ms_per_step': 1e3 * t_host / args.steps, 'hipgraph': bool(ae.use_graph),
     }
     peak = 2500.0 if args.dtype == 'bf16' else 157.3
     traffic = None
@@ -225,7 +242,7 @@ def main():
         out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic, 'traffic_unit': 'bytes/launch',
                            'kernel': 'gemm_conv_kernel<%s>' % ('bf16' if args.dtype == 'bf16' else 'float'),
                            'launches_timed': n, 'avg_launch_ms': ms / n, 'avg_launch_gflop': fl / n / 1e9,
-                           'share_of_step': ms / (1e3 * dt)}
+                           'measured_on': ('instrumented eager steps after the timed region' if ae.use_graph else 'the timed steps')}
     else:
         out['roofline'] = {'bound': 'mfma', 'achieved': None, 'peak': peak, 'unit': 'TFLOP/s', 'frac': None, 'traffic': None}
     out['step_tflops'] = 180.7e6 * value / 1e12          # 180.7 MFLOP per frame for the whole step

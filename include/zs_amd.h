@@ -159,6 +159,7 @@ typedef struct {
   int32_t B, T, C; float eps;
   float drop_p; uint64_t seed; uint32_t stream_id; const uint8_t* mask; int64_t mask_ld;
   int32_t res_mode; const void* res; int64_t ldres; int32_t T_res; int32_t res_pad_mode;
+  const uint64_t* seed_ptr;      /* optional device scalar added to `seed` (graph replay: see zs_step_counters) */
 } ZsInstNormFwd;
 int zs_instnorm_fwd(const ZsInstNormFwd* p, void* stream);
 
@@ -173,6 +174,7 @@ typedef struct {
   int32_t B, T, C;
   float drop_p; uint64_t seed; uint32_t stream_id; const uint8_t* mask; int64_t mask_ld;
   float slope;
+  const uint64_t* seed_ptr;
 } ZsInstNormBwd;
 int zs_instnorm_bwd(const ZsInstNormBwd* p, void* stream);
 
@@ -220,6 +222,7 @@ typedef struct {
   void* bits; int64_t ld_bits; int32_t bits_fill_cols;
   float* bits_f32;               /* optional compact [rows][E] fp32 copy (API output) */
   float* y0;                     /* optional [rows][E] */
+  const uint64_t* seed_ptr;      /* optional device scalar added to `seed` */
 } ZsMbvFwd;
 int zs_mbv_fwd(const ZsMbvFwd* p, void* stream);
 typedef struct {
@@ -292,8 +295,13 @@ typedef struct {
   float* p; float* g; float* m; float* v; int64_t n;
   float lr, beta1, beta2, eps, bc1, bc2;
   const float* sumsq; float max_norm; int32_t write_clipped_grad;
+  const int32_t* step_ptr;       /* optional device step count t: bc1 = 1-beta1^t, bc2 = 1-beta2^t computed on device */
 } ZsAdam;
 int zs_adam_clip(const ZsAdam* p, void* stream);
+
+/* zs_step_counters: per-step device-side state for hipGraph replay (kernel arguments are frozen in a graph):
+ * *seed += 0x9E3779B97F4A7C15, *step += 1.  Either pointer may be null. */
+int zs_step_counters(uint64_t* seed, int32_t* step, void* stream);
 
 /* zs_softmax_ce: nn.CrossEntropyLoss (mean) + gradient (trainer.py:297-304). logits fp32 [B][ld]. */
 typedef struct {

@@ -343,3 +343,30 @@ def test_adversarial_steps_vs_oracle(dev):
     cs.optimizer_step()
     torch.cuda.synchronize()
     assert all(torch.isfinite(p).all() for p in clf.parameters())
+
+
+def test_graph_replay_equals_eager(dev):
+    """hipGraph capture/replay of the training step: bit-identical loss trajectory and parameters to the same
+    launches issued eagerly (device-side seed and Adam step count), and the noise really changes between steps."""
+    from zs_amd.model import Decoder, Encoder
+    from zs_amd.trainer import AEStep
+    res = []
+    for graph_warmup in (2, 10 ** 9):
+        torch.manual_seed(0)
+        enc = Encoder(c_in=80, c_h1=16, c_h2=64, c_h3=32, ns=0.01, dp=0.5, enc_size=32, seg_len=128, enc_mode='multilabel_binary',
+                      dtype='bf16').to(dev)
+        dec = Decoder(c_in=32, c_out=80, c_h=64, c_a=4, ns=0.01, seg_len=128, dtype='bf16').to(dev)
+        ae = AEStep(enc, dec, lr=1e-3, max_grad_norm=5.0, use_graph=True)
+        ae.graph_warmup = graph_warmup
+        g = torch.Generator().manual_seed(1)
+        losses = []
+        for i in range(7):
+            x = torch.rand(4, 128, 80, generator=g).to(dev)
+            c = torch.randint(0, 4, (4,), generator=g).to(dev)
+            losses.append(ae.step(x, c).item())
+        res.append((losses, enc.flat_params()[0].clone(), dec.flat_params()[0].clone(), len(ae._graphs)))
+    (la, ea, da, na), (lb, eb, db, nb) = res
+    assert na == 1 and nb == 0
+    assert la == lb, (la, lb)
+    assert torch.equal(ea, eb) and torch.equal(da, db)
+    assert len(set(la)) == len(la)

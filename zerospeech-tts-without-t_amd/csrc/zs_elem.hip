@@ -76,6 +76,7 @@ __global__ void emb_scatter_kernel(const ZsEmbScatter p) {
 template <typename T>
 __global__ void mbv_fwd_kernel(const ZsMbvFwd p) {
   const int64_t total = p.rows * p.bits_fill_cols;
+  const uint64_t seed = p.seed + (p.seed_ptr ? *p.seed_ptr : 0ull);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / p.bits_fill_cols;
     const int e = (int)(i - r * p.bits_fill_cols);
@@ -90,7 +91,7 @@ __global__ void mbv_fwd_kernel(const ZsMbvFwd p) {
       else {
         float u0, u1;
         if (p.noise_kind == 1) { u0 = p.noise[ni]; u1 = p.noise[ni + 1]; }
-        else { u0 = zs_uniform(p.seed, 0x6d627600u, (uint64_t)ni); u1 = zs_uniform(p.seed, 0x6d627600u, (uint64_t)ni + 1); }
+        else { u0 = zs_uniform(seed, 0x6d627600u, (uint64_t)ni); u1 = zs_uniform(seed, 0x6d627600u, (uint64_t)ni + 1); }
         g0 = -logf(-logf(u0 + 1e-20f) + 1e-20f);                 // model/model.py:95-98
         g1 = -logf(-logf(u1 + 1e-20f) + 1e-20f);
       }
@@ -188,8 +189,14 @@ __global__ void adam_kernel(const ZsAdam p) {
     const float norm = sqrtf(*p.sumsq);
     coef = fminf(p.max_norm / (norm + 1e-6f), 1.f);              // clip_grad_norm_
   }
-  const float step_size = p.lr / p.bc1;
-  const float bc2_sqrt = sqrtf(p.bc2);
+  float bc1 = p.bc1, bc2 = p.bc2;
+  if (p.step_ptr) {                                              // hipGraph replay: the step count lives on the device
+    const float t = (float)(*p.step_ptr);
+    bc1 = 1.f - powf(p.beta1, t);
+    bc2 = 1.f - powf(p.beta2, t);
+  }
+  const float step_size = p.lr / bc1;
+  const float bc2_sqrt = sqrtf(bc2);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * blockDim.x) {
     const float g = p.g[i] * coef;
     float m = p.m[i], v = p.v[i];
@@ -199,6 +206,13 @@ __global__ void adam_kernel(const ZsAdam p) {
     p.p[i] = p.p[i] - step_size * (m / denom);
     p.m[i] = m; p.v[i] = v;
     if (p.write_clipped_grad) p.g[i] = g;
+  }
+}
+
+__global__ void step_counters_kernel(uint64_t* seed, int32_t* step) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (seed) *seed += 0x9E3779B97F4A7C15ull;
+    if (step) *step += 1;
   }
 }
 
@@ -324,9 +338,15 @@ extern "C" int zs_sqnorm(const float* g, int64_t n, double* partial, float* out_
 
 extern "C" int zs_adam_clip(const ZsAdam* p, void* stream) {
   ZS_REQUIRE(p && p->p && p->g && p->m && p->v && p->n > 0, "zs_adam_clip: bad args");
-  ZS_REQUIRE(p->bc1 > 0.f && p->bc2 > 0.f, "zs_adam_clip: bias corrections");
+  ZS_REQUIRE(p->step_ptr || (p->bc1 > 0.f && p->bc2 > 0.f), "zs_adam_clip: bias corrections");
   hipLaunchKernelGGL(adam_kernel, dim3(nblocks(p->n, 4096)), dim3(NTE), 0, (hipStream_t)stream, *p);
   return zs_check_launch("zs_adam_clip");
+}
+
+extern "C" int zs_step_counters(uint64_t* seed, int32_t* step, void* stream) {
+  ZS_REQUIRE(seed || step, "zs_step_counters: bad args");
+  hipLaunchKernelGGL(step_counters_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, seed, step);
+  return zs_check_launch("zs_step_counters");
 }
 
 extern "C" int zs_softmax_ce(const ZsSoftmaxCE* p, void* stream) {

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(NTN) void instnorm_fwd_kernel(const ZsInstNormFwd p
     for (int k = 0; k < 8; ++k) { p.mean[(int64_t)b * p.C + c0 + k] = mean[k]; p.rstd[(int64_t)b * p.C + c0 + k] = rstd[k]; }
   }
   const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+  const uint64_t seed = p.seed + (p.seed_ptr ? *p.seed_ptr : 0ull);
   float e2[8];
   if (p.out2) {
     const int64_t vi = p.idx ? p.idx[b] : 0;
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(NTN) void instnorm_fwd_kernel(const ZsInstNormFwd p
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       o[k] = (v[i][k] - mean[k]) * rstd[k];
-      o[k] *= keep_scale(p.mask, p.mask_ld, p.drop_p, p.seed, p.stream_id, row, c0 + k, p.C, inv_keep);
+      o[k] *= keep_scale(p.mask, p.mask_ld, p.drop_p, seed, p.stream_id, row, c0 + k, p.C, inv_keep);
     }
     if (p.res_mode == ZS_RES_IDENTITY) {
       float r[8]; load8<T>(res + row * p.ldres + c0, r);
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(NTN) void instnorm_bwd_kernel(const ZsInstNormBwd p
     rstd[k] = cvalid ? p.rstd[(int64_t)b * p.C + c0 + k] : 0.f;
   }
   const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+  const uint64_t seed = p.seed + (p.seed_ptr ? *p.seed_ptr : 0ull);
   float g[RPT][8], xv[RPT][8];
   float sg[8], sgx[8];
 #pragma unroll
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(NTN) void instnorm_bwd_kernel(const ZsInstNormBwd p
       load8<T>((const T*)p.x + row * p.ldx + c0, xv[i]);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        g[i][k] *= keep_scale(p.mask, p.mask_ld, p.drop_p, p.seed, p.stream_id, row, c0 + k, p.C, inv_keep);
+        g[i][k] *= keep_scale(p.mask, p.mask_ld, p.drop_p, seed, p.stream_id, row, c0 + k, p.C, inv_keep);
         const float xh = (xv[i][k] - mean[k]) * rstd[k];
         sg[k] += g[i][k]; sgx[k] += g[i][k] * xh;
       }

@@ -52,7 +52,7 @@ class EncoderEngine(object):
         self.gru.pack()
 
     # ------------------------------------------------------------------------------------------
-    def forward(self, x, training, noise=None, noise_kind=2, seed=0, drop_masks=None):
+    def forward(self, x, training, noise=None, noise_kind=2, seed=0, drop_masks=None, seed_ptr=None):
         """x: fp32 [B, T, c_in] contiguous on device.  Returns (bits Act [B,T',E] (T dtype, feeds the decoder),
         bits_f32 [B,T',E], logits_f32 [B,T',ld]).  noise: fp32 [B,T',E,2] (Gumbel if noise_kind 0, uniform if 1)."""
         c, ns = self.ctx, self.ns
@@ -65,7 +65,7 @@ class EncoderEngine(object):
         Ts = [T, _half_up(T), _half_up(_half_up(T)), _half_up(_half_up(_half_up(T)))]
         T4 = Ts[3]
         tag = '_%d_%d_%d' % (self.uid, B, T)
-        tp = {'B': B, 'T': T, 'Ts': Ts, 'training': training, 'seed': seed, 'masks': masks, 'dp': dp}
+        tp = {'B': B, 'T': T, 'Ts': Ts, 'training': training, 'seed': seed, 'masks': masks, 'dp': dp, 'seed_ptr': seed_ptr}
 
         xin = c.act('e_xin' + tag, B, T, F)
         cat = c.act('e_cat' + tag, B, T, self.ncat)
@@ -108,7 +108,7 @@ class EncoderEngine(object):
         bits_f32 = c.f32('e_bitsf' + tag, B * T4 * E)
         y0 = c.f32('e_y0' + tag, B * T4 * E)
         L.call('zs_mbv_fwd', 'ZsMbvFwd', st, dtype=c.dt, logits=logits.ptr(), ld=logits.ld, logits_f32=1,
-               noise=L.ptr(noise), noise_kind=noise_kind, seed=seed, rows=B * T4, E=E, tau=0.1, bits=bits.ptr(),
+               noise=L.ptr(noise), noise_kind=noise_kind, seed=seed, seed_ptr=seed_ptr, rows=B * T4, E=E, tau=0.1, bits=bits.ptr(),
                ld_bits=bits.ld, bits_fill_cols=bits.ld, bits_f32=L.ptr(bits_f32), y0=L.ptr(y0))               # :476-480
         tp.update(cat2=cat2, gates=gates, y0=y0, T4=T4, gru_in=a, logits=logits)
         self.tape = tp
@@ -127,7 +127,7 @@ class EncoderEngine(object):
                mean=L.ptr(mean), rstd=L.ptr(rstd), B=B, T=T, C=C, eps=EPS_IN, drop_p=tp['dp'], seed=tp['seed'],
                stream_id=k + 1, mask=L.ptr(m), mask_ld=(m.shape[-1] if m is not None else 0), res_mode=res_mode,
                res=(res.ptr() if res is not None else None), ldres=(res.ld if res is not None else 0),
-               T_res=(res.T if res is not None else 0), res_pad_mode=self.pad_mode)
+               T_res=(res.T if res is not None else 0), res_pad_mode=self.pad_mode, seed_ptr=tp.get('seed_ptr'))
         return (mean, rstd, k)
 
     def _in_bwd(self, dout, x, stt, dz, tp):
@@ -136,7 +136,8 @@ class EncoderEngine(object):
         m = tp['masks'][k]
         L.call('zs_instnorm_bwd', 'ZsInstNormBwd', c.stream, dtype=c.dt, dout=dout.ptr(), ldd=dout.ld, x=x.ptr(), ldx=x.ld,
                mean=L.ptr(mean), rstd=L.ptr(rstd), dz=dz.ptr(), ldz=dz.ld, B=x.B, T=x.T, C=x.ld, drop_p=tp['dp'],
-               seed=tp['seed'], stream_id=k + 1, mask=L.ptr(m), mask_ld=(m.shape[-1] if m is not None else 0), slope=self.ns)
+               seed=tp['seed'], stream_id=k + 1, mask=L.ptr(m), mask_ld=(m.shape[-1] if m is not None else 0), slope=self.ns,
+               seed_ptr=tp.get('seed_ptr'))
 
     # ------------------------------------------------------------------------------------------
     def backward(self, dbits, dlogits_extra=None):

@@ -66,6 +66,15 @@ class ZsModule(nn.Module):
     def mark_dirty(self):
         self._zs['version'] = None
 
+    def repack(self):
+        """Re-pack the GEMM operands from the fp32 master weights now (stream-ordered) and mark them current."""
+        z = self._zs
+        if z['engine'] is None:
+            self._engine()
+        else:
+            z['engine'].pack()
+            z['version'] = sum(p._version for p in self.parameters())
+
     def set_compute_dtype(self, dtype):
         if dtype != self._zs_dtype:
             self._zs_dtype = dtype

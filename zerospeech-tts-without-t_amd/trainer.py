@@ -25,9 +25,15 @@ from .utils import Logger
 class AEStep(object):
     """The fused --train_ae iteration (trainer.py:322-332) for one Encoder/Decoder pair:
     fwd, L1, bwd, gradient all-reduce, per-net clip (utils.py:53-55) and Adam(betas=(0.5,0.9)) over both nets
-    (trainer.py:65-66).  All state lives on the device; nothing here synchronises with the host."""
+    (trainer.py:65-66).  All state lives on the device; nothing here synchronises with the host.
 
-    def __init__(self, encoder, decoder, lr=1e-4, betas=(0.5, 0.9), max_grad_norm=5.0):
+    Graph mode (ZS_GRAPH=1, default): after two eager warm-up steps the ~600 kernel launches of a step are captured
+    into hipGraphs and replayed, so the host cost per step is a handful of calls instead of ~15 ms of Python/ctypes
+    launches.  Everything that changes from step to step lives in device memory (RNG seed, Adam step count:
+    zs_step_counters).  With more than one rank the step is three graphs (fwd + decoder bwd | encoder bwd | optimizer)
+    with the RCCL all-reduces launched eagerly between them, so the decoder's reduce still overlaps the encoder bwd."""
+
+    def __init__(self, encoder, decoder, lr=1e-4, betas=(0.5, 0.9), max_grad_norm=5.0, use_graph=None):
         self.Encoder, self.Decoder = encoder, decoder
         self.lr, self.betas, self.max_grad_norm = float(lr), betas, float(max_grad_norm)
         self.adam_step = 0
@@ -41,40 +47,140 @@ class AEStep(object):
                                    part=torch.zeros(1024, dtype=torch.float64, device=dev))
         self._loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self._lpart = torch.zeros(1024, dtype=torch.float32, device=dev)
+        self._seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)      # uint64 bits, advanced by zs_step_counters
+        self._step_dev = torch.zeros(1, dtype=torch.int32, device=dev)      # Adam step count on the device
         self.reducer = parallel.GradReducer()
         self.xdec = None
+        self.use_graph = (os.environ.get('ZS_GRAPH', '1') == '1') if use_graph is None else bool(use_graph)
+        self._graphs = {}            # (B, T, F) -> dict(graphs=[...], x=static x, c=static c)
+        self._eager_calls = 0
+        self.graph_warmup = 2        # eager steps (same launches) before the capture
+
+    # ---- the three stream-ordered segments of a step -------------------------------------------------------------
+    def _seg_forward_decbwd(self, x_btf, c, noise, noise_kind, drop_masks, seed, seed_ptr):
+        enc, dec = self.Encoder, self.Decoder
+        ee, de = enc._engine(), dec._engine()
+        ctx = ee.ctx
+        B, T, F = x_btf.shape
+        bits, _, _ = ee.forward(x_btf, True, noise=noise, noise_kind=noise_kind, seed=seed, drop_masks=drop_masks, seed_ptr=seed_ptr)
+        xdec = de.forward(bits, c, True)
+        dlogit = de.ctx.act('t_dlogit_%d_%d' % (B, T), B, xdec.T, F)
+        L.call('zs_l1_loss', 'ZsL1Loss', ctx.stream, dtype=ctx.dt, x_dec=xdec.ptr(), ld_dec=xdec.ld, x=L.ptr(x_btf), ldx=F,
+               rows=B * xdec.T, F=F, dlogits=dlogit.ptr(), ldg=dlogit.ld, fill_cols=dlogit.ld, partial=L.ptr(self._lpart),
+               loss_out=L.ptr(self._loss), grad_scale=1.0)                                   # trainer.py:328
+        self._dbits = de.backward(dlogit)                                                    # loss.backward(), trainer.py:330
+        self.xdec = xdec
+
+    def _seg_encbwd(self):
+        self.Encoder._engine().backward(self._dbits)
+        join_side(self.device)
 
     def step(self, x_btf, c, noise=None, noise_kind=2, drop_masks=None, seed=None, update=True):
         """x_btf: fp32 [B, T, F] on the device (the loader's native layout), c: int64 [B].
         Returns the device scalar holding loss_rec."""
         enc, dec = self.Encoder, self.Decoder
         enc.train(); dec.train()
-        ee, de = enc._engine(), dec._engine()
-        ctx = ee.ctx
-        st = ctx.stream
-        B, T, F = x_btf.shape
+        multi = parallel.world_size() > 1
+        plain = noise is None and drop_masks is None and seed is None and update
+        if plain and self.use_graph:
+            return self._graph_step(x_btf, c, multi)
         if seed is None:
             seed = (self.adam_step + 1) * 0x9E3779B97F4A7C15 % (1 << 63) + parallel.rank()
-        bits, _, _ = ee.forward(x_btf, True, noise=noise, noise_kind=noise_kind, seed=seed, drop_masks=drop_masks)
-        xdec = de.forward(bits, c, True)
-        dlogit = de.ctx.act('t_dlogit_%d_%d' % (B, T), B, xdec.T, F)
-        L.call('zs_l1_loss', 'ZsL1Loss', st, dtype=ctx.dt, x_dec=xdec.ptr(), ld_dec=xdec.ld, x=L.ptr(x_btf), ldx=F,
-               rows=B * xdec.T, F=F, dlogits=dlogit.ptr(), ldg=dlogit.ld, fill_cols=dlogit.ld, partial=L.ptr(self._lpart),
-               loss_out=L.ptr(self._loss), grad_scale=1.0)                                   # trainer.py:328
-        dbits = de.backward(dlogit)                                                          # loss.backward(), trainer.py:330
-        multi = parallel.world_size() > 1
+        self._seg_forward_decbwd(x_btf, c, noise, noise_kind, drop_masks, seed, None)
         if multi:
             join_side(self.device)                 # decoder weight gradients (side stream) must be complete
             self.reducer.start(dec.flat_params()[1])
-        ee.backward(dbits)
-        join_side(self.device)
+        self._seg_encbwd()
         if multi:
             self.reducer.start(enc.flat_params()[1])
             self.reducer.finish()
-        self.xdec = xdec
         if update:
             self.optimizer_step()
         return self._loss
+
+    # ---- graph mode ------------------------------------------------------------------------------------------------
+    def _counted_step_eager(self, x_btf, c, multi):
+        """Same launches as the captured step (device-side seed / step count), executed eagerly."""
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        enc, dec = self.Encoder, self.Decoder
+        L.check(L.lib().zs_step_counters(L.ptr(self._seed_dev), L.ptr(self._step_dev), st), 'zs_step_counters')
+        self._seg_forward_decbwd(x_btf, c, None, 2, None, parallel.rank(), L.ptr(self._seed_dev))
+        if multi:
+            join_side(self.device)
+            self.reducer.start(dec.flat_params()[1])
+        self._seg_encbwd()
+        if multi:
+            self.reducer.start(enc.flat_params()[1])
+            self.reducer.finish()
+        self._optimizer_device_step()
+
+    def _optimizer_device_step(self):
+        """clip + Adam with the step count read from device memory, then re-pack the GEMM operands."""
+        self.grad_norms()
+        b1, b2 = self.betas
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        for name, net in (('enc', self.Encoder), ('dec', self.Decoder)):
+            o = self._opt[name]
+            flat, gflat = net.flat_params()
+            L.call('zs_adam_clip', 'ZsAdam', st, p=L.ptr(flat), g=L.ptr(gflat), m=L.ptr(o['m']), v=L.ptr(o['v']),
+                   n=flat.numel(), lr=self.lr, beta1=b1, beta2=b2, eps=1e-8, bc1=1.0, bc2=1.0, sumsq=L.ptr(o['sq']),
+                   max_norm=self.max_grad_norm, write_clipped_grad=0, step_ptr=L.ptr(self._step_dev))
+            net.repack()
+        self.adam_step += 1
+
+    def _graph_step(self, x_btf, c, multi):
+        key = tuple(x_btf.shape)
+        ent = self._graphs.get(key)
+        if ent is None:
+            if self._eager_calls < self.graph_warmup:          # warm-up: allocate every buffer, grow the workspaces
+                self._eager_calls += 1
+                self._counted_step_eager(x_btf, c, multi)
+                return self._loss
+            ent = self._capture(x_btf, c, multi)
+            self._graphs[key] = ent
+        ent['x'].copy_(x_btf, non_blocking=True)
+        ent['c'].copy_(c, non_blocking=True)
+        if not multi:
+            ent['graphs'][0].replay()
+        else:
+            g1, g2, g3 = ent['graphs']
+            enc, dec = self.Encoder, self.Decoder
+            g1.replay()
+            self.reducer.start(dec.flat_params()[1])
+            g2.replay()
+            self.reducer.start(enc.flat_params()[1])
+            self.reducer.finish()
+            g3.replay()
+        self.adam_step += 1
+        return self._loss
+
+    def _capture(self, x_btf, c, multi):
+        xs, cs = x_btf.clone(), c.clone()
+        torch.cuda.synchronize(self.device)
+        st_ptr = L.ptr(self._seed_dev)
+        graphs = []
+        step0 = self.adam_step
+
+        def seg1():
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            L.check(L.lib().zs_step_counters(L.ptr(self._seed_dev), L.ptr(self._step_dev), st), 'zs_step_counters')
+            self._seg_forward_decbwd(xs, cs, None, 2, None, parallel.rank(), st_ptr)
+            if multi:
+                join_side(self.device)
+
+        def seg3():
+            self._optimizer_device_step()
+            self.adam_step = step0                             # capture does not execute: the caller counts the step
+
+        pool = None
+        segs = [lambda: (seg1(), self._seg_encbwd(), seg3())] if not multi else [seg1, self._seg_encbwd, seg3]
+        for seg in segs:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                seg()
+            pool = g.pool()
+            graphs.append(g)
+        return {'graphs': graphs, 'x': xs, 'c': cs}
 
     def grad_norms(self):
         """Squared per-net gradient norms as device scalars (Encoder, Decoder are clipped separately)."""
@@ -101,6 +207,7 @@ class AEStep(object):
                    n=flat.numel(), lr=self.lr, beta1=b1, beta2=b2, eps=1e-8, bc1=bc1, bc2=bc2, sumsq=L.ptr(o['sq']),
                    max_norm=self.max_grad_norm, write_clipped_grad=0)
             net.mark_dirty()
+        self._step_dev.fill_(self.adam_step)
 
 
 class ClfStep(object):
