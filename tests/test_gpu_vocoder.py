@@ -129,3 +129,53 @@ def test_convert_and_encode_pipeline_vs_oracle(cv, tmp_path):
     tr2.load_model(str(tmp_path / 'm.pth-ae-1000'), hps.load_model_list, verbose=False)
     for (k, a), (_, b) in zip(tr.Decoder.state_dict().items(), tr2.Decoder.state_dict().items()):
         assert torch.equal(a, b)
+
+
+def test_batched_encode_resynthesis_64_utterances(cv, tmp_path):
+    """BASELINE config 4 shape: 64 utterances of 200..700 frames, batched fragments + batched Griffin-Lim.
+    * batched encodings / spectrograms equal the per-fragment (reference-style) path given the same Gumbel noise
+    * a sample of utterances is checked against the oracle (bits: identical up to near-ties; spectrogram 1e-3)
+    * output lengths follow the fragment rule and the 200*(T-1) sample law."""
+    import zs_oracle as O
+    from zs_amd.hps import make_hps
+    from zs_amd.trainer import Trainer
+    torch.manual_seed(1)
+    hps = make_hps(enc_size=16, emb_size=32, n_speakers=4, n_target_speakers=2)
+    tr = Trainer(hps, None, 'targeted_residual', 'multilabel_binary', log_dir=str(tmp_path / 'log'), dtype='fp32')
+    rng = np.random.RandomState(0)
+    lens = rng.randint(200, 701, size=64)
+    specs = [np.clip(rng.rand(int(n), 513).astype(np.float32), 1e-8, 1) for n in lens]
+    spk = [int(rng.randint(0, 4)) for _ in specs]
+    store = {}
+
+    def noise_fn(n, Tp, E):                                   # deterministic noise keyed by (Tp, call count)
+        g = torch.Generator().manual_seed(1000 * Tp + len([k for k in store if k[0] == Tp]))
+        G = O.gumbel_from_uniform(torch.rand(n, Tp, E, 2, generator=g))
+        store[(Tp, len([k for k in store if k[0] == Tp]))] = G
+        return G
+
+    encs, decs = cv.encode_batch(specs, tr, 128, decode_speakers=spk, noise_fn=noise_fn)
+    assert len(encs) == 64 and len(decs) == 64
+    for n, e, d in zip(lens, encs, decs):
+        frags = O.fragment_plan(int(n), 128)[1]
+        t_out = sum(O.out_len(b - a) for a, b in frags)
+        assert d.shape == (t_out, 513) and e.shape == (t_out // 8, 16) and set(np.unique(e)) <= {0.0, 1.0}
+    # oracle on 3 sampled 128-frame fragments with the very noise rows the batch used
+    esd = {k: v.detach().cpu() for k, v in tr.Encoder.state_dict().items()}
+    dsd = {k: v.detach().cpu() for k, v in tr.Decoder.state_dict().items()}
+    G128 = store[(16, 0)]
+    order = [u for u in range(64)]                            # fragments of length 128 in batch order: (u, k) sorted by utterance
+    frag128 = [(u, k, a, b) for u in order for k, (a, b) in enumerate(O.fragment_plan(int(lens[u]), 128)[1]) if b - a == 128]
+    flips = total = 0
+    for i in (0, 7, 100):
+        u, k, a, b = frag128[i]
+        x = torch.from_numpy(specs[u][a:b]).unsqueeze(0).permute(0, 2, 1)
+        with torch.no_grad():
+            o_act, _ = O.encoder_forward(esd, x, hps.ns, hps.enc_dp, 16, 128, G=G128[i:i + 1])
+            o_dec = O.decoder_forward(dsd, torch.from_numpy(encs[u][16 * k:16 * k + 16].T.copy()).unsqueeze(0), torch.tensor([spk[u]]), hps.ns, 128)
+        flips += int((o_act[0].numpy().T != encs[u][16 * k:16 * k + 16]).sum()); total += 16 * 16
+        assert np.abs(o_dec[0].numpy().T - decs[u][128 * k:128 * k + 128]).max() < 1e-3
+    assert flips <= total // 50
+    wavs = cv.spectrogram2wav_batch(decs[:16], n_iter=20, do_trim=False)
+    for d, w in zip(decs[:16], wavs):
+        assert w.shape == (200 * (d.shape[0] - 1),) and np.isfinite(w).all()

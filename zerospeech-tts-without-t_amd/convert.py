@@ -219,6 +219,52 @@ def encode(src_speaker_spec, trainer, seg_len, s_speaker=None, utt_id=None, resu
         return encodings
 
 
+def encode_batch(specs, trainer, seg_len, decode_speakers=None, noise_fn=None, max_batch=256):
+    """Batched encode()/convert() for many utterances: the same fragments the reference would send through the
+    network one by one (convert.py:151-165) are grouped by length and run as batches on the GPU.
+    specs: list of [T_i, 513] arrays.  decode_speakers: optional list of target speaker ids -> also returns the decoded
+    spectrograms (enc_only path of convert()).  noise_fn(n_frag, T', E) -> Gumbel noise [n, T', E, 2] or None makes the
+    stochastic discretiser reproducible.  Returns (encodings list, decoded list or None)."""
+    trainer.set_eval()
+    enc, dec = trainer.Encoder, trainer.Decoder
+    dev = trainer.device
+    items = []                                            # (utt, order, start, stop, truncate)
+    padded = []
+    for u, spec in enumerate(specs):
+        spec, was_padded = _pad_min(np.asarray(spec, dtype=np.float32))
+        padded.append(spec)
+        if len(spec) <= seg_len:
+            items.append((u, 0, 0, len(spec), (MIN_LEN // 8) if was_padded else None))
+        else:
+            for k, (a, b) in enumerate(fragments(len(spec), seg_len)):
+                items.append((u, k, a, b, None))
+    by_len = {}
+    for it in items:
+        by_len.setdefault(it[3] - it[2], []).append(it)
+    enc_out, dec_out = {}, {}
+    for Tf, group in sorted(by_len.items()):
+        for lo in range(0, len(group), max_batch):
+            chunk = group[lo:lo + max_batch]
+            x = torch.from_numpy(np.stack([padded[u][a:b] for (u, _, a, b, _) in chunk])).to(dev)        # [n, Tf, 513]
+            G = noise_fn(len(chunk), ((((Tf + 1) // 2 + 1) // 2) + 1) // 2, enc.enc_size) if noise_fn is not None else None
+            act, _ = enc(x.permute(0, 2, 1), G=G)
+            if decode_speakers is not None:
+                c = torch.tensor([decode_speakers[u] for (u, _, _, _, _) in chunk], dtype=torch.int64, device=dev)
+                xd = dec(act, c).permute(0, 2, 1).cpu().numpy()
+            e = act.permute(0, 2, 1).cpu().numpy()
+            for i, (u, k, _, _, trunc) in enumerate(chunk):
+                enc_out[(u, k)] = e[i][:trunc] if trunc is not None else e[i]
+                if decode_speakers is not None:
+                    dec_out[(u, k)] = xd[i]
+    encs, decs = [], ([] if decode_speakers is not None else None)
+    for u in range(len(specs)):
+        ks = sorted(k for (uu, k) in enc_out if uu == u)
+        encs.append(np.concatenate([enc_out[(u, k)] for k in ks], axis=0))
+        if decs is not None:
+            decs.append(np.concatenate([dec_out[(u, k)] for k in ks], axis=0))
+    return encs, decs
+
+
 def write_wav(path, wav, sr):
     """16-bit PCM mono wav (the reference uses soundfile.write(..., 'PCM_16'), convert.py:174)."""
     import wave

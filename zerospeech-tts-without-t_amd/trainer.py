@@ -82,7 +82,8 @@ class AEStep(object):
         enc.train(); dec.train()
         multi = parallel.world_size() > 1
         plain = noise is None and drop_masks is None and seed is None and update
-        if plain and self.use_graph:
+        # multi-rank: graphs are opt-in (ZS_GRAPH_MULTI=1); the eager path keeps the standard async all-reduce flow
+        if plain and self.use_graph and (not multi or os.environ.get('ZS_GRAPH_MULTI', '0') == '1'):
             return self._graph_step(x_btf, c, multi)
         if seed is None:
             seed = (self.adam_step + 1) * 0x9E3779B97F4A7C15 % (1 << 63) + parallel.rank()
@@ -176,7 +177,7 @@ class AEStep(object):
         segs = [lambda: (seg1(), self._seg_encbwd(), seg3())] if not multi else [seg1, self._seg_encbwd, seg3]
         for seg in segs:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):   # other threads (RCCL watchdog) may call HIP
                 seg()
             pool = g.pool()
             graphs.append(g)
