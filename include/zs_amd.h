@@ -38,6 +38,12 @@ enum { ZS_RES_NONE = 0, ZS_RES_IDENTITY = 1, ZS_RES_AVGPOOL2 = 2, ZS_RES_UPSAMPL
 
 int zs_abi_version(void);
 const char* zs_last_error(void);
+/* Kernel-selection knobs (defaults also read from the environment at first use):
+ *   "gemm_dma" (ZS_GEMM_DMA, 1): LDS-DMA operand staging; 0 = register-staged kernel
+ *   "gemm_ring" (ZS_GEMM_RING, 1): allow the 256x128 3-stage-ring kernel
+ *   "gemm_ring_min_tiles" (ZS_GEMM_RING_MIN_TILES, 256): use it when the problem has at least that many 256x128 tiles
+ * Returns the previous value, or ZS_EINVAL for an unknown key. */
+int zs_set_option(const char* key, int value);
 
 /* ---------------------------------------------------------------------------------------------
  * zs_gemm_conv: implicit-GEMM Conv1d / Linear / transposed-conv (data gradient) on MFMA.

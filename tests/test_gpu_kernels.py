@@ -75,18 +75,28 @@ def _ref_conv(x_btc, w, b, stride, reflect):
     return F.conv1d(xp, w3, b, stride=stride).permute(0, 2, 1)
 
 
+@pytest.fixture(params=['ring', 'dma', 'reg'])
+def gemm_variant(request, zs):
+    """Run a test with each of the three conv-GEMM kernels: 256x128 3-stage ring, 128x128 LDS-DMA, 128x128 register-staged."""
+    L, _ = zs
+    want = {'ring': (1, 1, 1), 'dma': (1, 0, 256), 'reg': (0, 0, 256)}[request.param]
+    old = (L.set_option('gemm_dma', want[0]), L.set_option('gemm_ring', want[1]), L.set_option('gemm_ring_min_tiles', want[2]))
+    yield request.param
+    L.set_option('gemm_dma', old[0]); L.set_option('gemm_ring', old[1]); L.set_option('gemm_ring_min_tiles', old[2])
+
+
 CONV_CASES = [
     # B, T, Cin, Cout, k, stride, reflect
     (2, 24, 80, 16, 1, 1, True), (2, 24, 80, 16, 2, 1, True), (2, 24, 80, 16, 3, 1, True), (2, 24, 80, 16, 4, 1, True),
     (2, 24, 80, 16, 5, 1, True), (2, 24, 80, 16, 6, 1, True), (2, 24, 80, 16, 7, 1, True),
     (3, 50, 513, 130, 7, 1, True), (2, 9, 32, 32, 5, 2, True), (2, 33, 64, 48, 5, 2, True), (5, 64, 96, 513, 1, 1, True),
-    (2, 20, 32, 40, 3, 1, False), (2, 21, 32, 40, 5, 2, False), (1, 300, 160, 256, 3, 1, True),
+    (2, 20, 32, 40, 3, 1, False), (2, 21, 32, 40, 5, 2, False), (1, 300, 160, 256, 3, 1, True), (3, 200, 64, 200, 3, 1, True),
 ]
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('case', CONV_CASES)
-def test_conv_fwd(zs, dtype, case):
+def test_conv_fwd(zs, dtype, case, gemm_variant):
     L, layers = zs
     B, T, Cin, Cout, k, stride, reflect = case
     g = torch.Generator().manual_seed(hash(case) % 1000)
@@ -109,7 +119,7 @@ def test_conv_fwd(zs, dtype, case):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-def test_conv_epilogue_split2_vec(zs, dtype):
+def test_conv_epilogue_split2_vec(zs, dtype, gemm_variant):
     """pixel_shuffle + speaker-embedding adds + dual output (decoder conv_block first conv)."""
     L, layers = zs
     B, T, C = 3, 10, 32
@@ -139,7 +149,7 @@ def test_conv_epilogue_split2_vec(zs, dtype):
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('case', [(2, 16, 32, 48, 5, 1), (2, 16, 32, 48, 5, 2), (3, 12, 64, 32, 3, 1), (2, 10, 40, 24, 1, 1),
                                   (2, 128, 96, 80, 5, 2)])
-def test_conv_backward(zs, dtype, case):
+def test_conv_backward(zs, dtype, case, gemm_variant):
     """dgrad (padded domain) + reflect fold + lrelu' ; wgrad ; bias grad -- against autograd."""
     L, layers = zs
     B, T, Cin, Cout, k, stride = case

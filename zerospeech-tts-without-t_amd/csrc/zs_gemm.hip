@@ -89,9 +89,10 @@ __device__ __forceinline__ void store_group(OT* base, int64_t row, int64_t ld, i
   }
 }
 
-template <typename T>
+template <typename T, int NTHREADS>
 __device__ __forceinline__ void gemm_epilogue(const ZsGemmConv& p, f32x16 (&acc)[2][2], float* sC, int M, int m0, int n0,
                                               int wm, int wn, int tid, int g) {
+  constexpr int ROWS_PER_PASS = NTHREADS / 16;      // 128-row tile with 256 threads, 256-row tile with 512: 8 passes
   const int lane = tid & 63;
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
@@ -125,7 +126,7 @@ __device__ __forceinline__ void gemm_epilogue(const ZsGemmConv& p, f32x16 (&acc)
 
 #pragma unroll 1
   for (int it = 0; it < 8; ++it) {
-    const int row = rr0 + 16 * it;
+    const int row = rr0 + ROWS_PER_PASS * it;
     const int m = m0 + row;
     if (m >= M) break;
     float v[8];
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_conv_kernel(const ZsGemmConv p) {
 #undef ZS_SWRITE
 #undef ZS_SET_TAP
 
-  gemm_epilogue<T>(p, acc, reinterpret_cast<float*>(smem), M, m0, n0, wm, wn, tid, g);
+  gemm_epilogue<T, NT>(p, acc, reinterpret_cast<float*>(smem), M, m0, n0, wm, wn, tid, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -498,7 +499,149 @@ __global__ __launch_bounds__(NT, 2) void gemm_conv_dma_kernel(const ZsGemmConv p
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
     __syncthreads();                                   // ... and everyone else's
   }
-  gemm_epilogue<T>(p, acc, reinterpret_cast<float*>(smem), M, m0, n0, wm, wn, tid, g);
+  gemm_epilogue<T, NT>(p, acc, reinterpret_cast<float*>(smem), M, m0, n0, wm, wn, tid, g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ring variant for problems that fill the chip: 256x128 tile, 512 threads (8 waves as 4x2, each 64x64), one
+// workgroup per CU, 3-stage LDS ring (48 KiB per stage: A 256 rows + W 128 rows of 128 B) fed by LDS-DMA with TWO
+// chunks (96 KiB per CU) in flight.  Measured on the 128x128 kernel: with the in-loop DMA removed it runs at
+// 1290 TFLOP/s, with it at 720 -- the global->LDS stream (bytes in flight x latency), not LDS or MFMA, bounds the
+// loop; this variant has 1.5x the bytes in flight and 0.75x the operand bytes per FLOP.
+//   iteration k:  s_waitcnt vmcnt(6|0)  (this wave's pieces of chunk k landed; chunk k+1 may still fly)
+//                 s_barrier             (everyone's pieces landed AND everyone finished reading stage (k-1)%3)
+//                 16 x ds_read_b128     (inline asm: hipcc orders any ds_read behind ALL outstanding LDS-DMA)
+//                 DMA chunk k+2 -> stage (k+2)%3 ;  s_waitcnt lgkmcnt(0) ;  16 MFMA
+// ------------------------------------------------------------------------------------------------
+constexpr int RBM = 256, RNT = 512;
+constexpr int RSTAGE = (RBM + BN) * 128;          // 49,152 B
+constexpr int RING_LDS = 3 * RSTAGE;              // 147,456 B  (>= epilogue staging 256*132*4 = 135,168 B)
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+template <typename T>
+__global__ __launch_bounds__(RNT, 2) void gemm_conv_ring_kernel(const ZsGemmConv p) {
+  constexpr int EPS = 16 / (int)sizeof(T);
+  constexpr int KC = ROWB / (int)sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g = blockIdx.z;
+  const T* __restrict__ A = (const T*)p.A + (int64_t)g * p.a_gstride;
+  const T* __restrict__ W = (const T*)p.W + (int64_t)g * p.w_gstride;
+  const int M = p.B * p.T_out;
+  const int ntn = (p.N + BN - 1) / BN;
+  const int ntm = (M + RBM - 1) / RBM;
+  const int wg = xcd_remap(blockIdx.x, ntm * ntn);
+  constexpr int GM = 4;                              // 4 x 256 rows: the 32 tiles resident on an XCD share panels
+  const int per_group = GM * ntn;
+  const int grp = wg / per_group;
+  const int gm = min(GM, ntm - grp * GM);
+  const int in_g = wg - grp * per_group;
+  const int m0 = (grp * GM + in_g % gm) * RBM, n0 = (in_g / gm) * BN;
+
+  // loader: per chunk this wave issues 4 A pieces (rows wave*32 + 8i + lane/8) and 2 W pieces (rows wave*16 + 8i + lane/8)
+  const int lrow = lane >> 3, slot = lane & 7;
+  int rb[4], rt[4], lseg[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wave * 32 + i * 8 + lrow;
+    lseg[i] = slot ^ ((r >> 1) & 7);
+    const int m = m0 + r;
+    if (m < M) { rb[i] = m / p.T_out; rt[i] = m - rb[i] * p.T_out; } else { rb[i] = -1; rt[i] = 0; }
+  }
+  const int chunks_per_tap = p.cin_pad / KC;
+  const T* zline = reinterpret_cast<const T*>(zs_zero_line);
+  const T *pa0, *pa1, *pa2, *pa3;
+  int inc0, inc1, inc2, inc3;
+#define ZS_SET_TAP(i, ptr, inc)                                                                         \
+  {                                                                                                     \
+    bool ok = false; int srow = 0;                                                                      \
+    if (rb[i] >= 0) srow = conv_src_row(p.gather, p.pad_mode, p.stride, p.pad_left, p.T_in, rt[i], tap, ok); \
+    ptr = ok ? (A + (int64_t)rb[i] * p.a_batch_stride + (int64_t)srow * p.lda + lseg[i] * EPS) : (zline + lseg[i] * EPS); \
+    inc = ok ? KC : 0;                                                                                  \
+  }
+  const int wr0 = wave * 16 + lrow, wr1 = wave * 16 + 8 + lrow;
+  const T* pw0 = W + (int64_t)(n0 + wr0) * p.ldw + (slot ^ ((wr0 >> 1) & 7)) * EPS;
+  const T* pw1 = W + (int64_t)(n0 + wr1) * p.ldw + (slot ^ ((wr1 >> 1) & 7)) * EPS;
+  const int nk = p.taps * chunks_per_tap;
+  int tap = 0, cit = 0;
+  { ZS_SET_TAP(0, pa0, inc0) ZS_SET_TAP(1, pa1, inc1) ZS_SET_TAP(2, pa2, inc2) ZS_SET_TAP(3, pa3, inc3) }
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto dma = [&](int stage) {
+    unsigned char* da = smem + stage * RSTAGE + wave * 4096;               // A rows wave*32 ..
+    unsigned char* db = smem + stage * RSTAGE + RBM * 128 + wave * 2048;   // W rows wave*16 ..
+    __builtin_amdgcn_global_load_lds((gptr_t)pa0, (lptr_t)(da), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)pa1, (lptr_t)(da + 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)pa2, (lptr_t)(da + 2048), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)pa3, (lptr_t)(da + 3072), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)pw0, (lptr_t)(db), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)pw1, (lptr_t)(db + 1024), 16, 0, 0);
+    pw0 += KC; pw1 += KC;
+    if (++cit == chunks_per_tap) {
+      cit = 0; ++tap;
+      if (tap < p.taps) { ZS_SET_TAP(0, pa0, inc0) ZS_SET_TAP(1, pa1, inc1) ZS_SET_TAP(2, pa2, inc2) ZS_SET_TAP(3, pa3, inc3) }
+    } else {
+      pa0 += inc0; pa1 += inc1; pa2 += inc2; pa3 += inc3;
+    }
+  };
+#undef ZS_SET_TAP
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addresses (LDS byte addresses): row = w*64 + mi*32 + (lane&31); slot = (2ks + lane>>5) ^ ((row>>1)&7)
+  const int frow = lane & 31, fh = lane >> 5, fx = (frow >> 1) & 7;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned a_lane = lds0 + (unsigned)((wm * 64 + frow) * 128);
+  const unsigned b_lane = lds0 + (unsigned)(RBM * 128 + (wn * 64 + frow) * 128);
+  unsigned koff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = (unsigned)(((2 * ks + fh) ^ fx) * 16);
+
+  dma(0);
+  if (nk > 1) dma(1);
+  int stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // chunk kt landed, chunk kt+1 (6 pieces) may fly
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const unsigned sa = a_lane + (unsigned)(stage * RSTAGE), sb = b_lane + (unsigned)(stage * RSTAGE);
+    u32x4_t fa[4][2], fb[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      asm volatile("ds_read_b128 %0, %1" : "=v"(fa[ks][0]) : "v"(sa + koff[ks]));
+      asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fa[ks][1]) : "v"(sa + koff[ks]));
+      asm volatile("ds_read_b128 %0, %1" : "=v"(fb[ks][0]) : "v"(sb + koff[ks]));
+      asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fb[ks][1]) : "v"(sb + koff[ks]));
+    }
+    if (kt + 2 < nk) {
+      int s2 = stage + 2; if (s2 >= 3) s2 -= 3;
+      dma(s2);                                   // stage (kt+2)%3 == (kt-1)%3: everybody finished reading it before the barrier
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);            // MFMAs (register-only) must stay below the wait
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const uint4 ua = make_uint4(fa[ks][mi].x, fa[ks][mi].y, fa[ks][mi].z, fa[ks][mi].w);
+          const uint4 ub = make_uint4(fb[ks][ni].x, fb[ks][ni].y, fb[ks][ni].z, fb[ks][ni].w);
+          Mma<T>::run(ua, ub, acc[mi][ni]);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    if (++stage == 3) stage = 0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                // all fragment reads done before the ring is reused as the staging tile
+  gemm_epilogue<T, RNT>(p, acc, reinterpret_cast<float*>(smem), M, m0, n0, wm, wn, tid, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -758,6 +901,14 @@ int pick_splits(const ZsGemmWgrad* p) {
 
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+int g_use_dma = -1, g_use_ring = -1, g_ring_min_tiles = -1;
+void init_options() {
+  if (g_use_dma < 0) g_use_dma = env_int("ZS_GEMM_DMA", 1);
+  if (g_use_ring < 0) g_use_ring = env_int("ZS_GEMM_RING", 1);
+  if (g_ring_min_tiles < 0) g_ring_min_tiles = env_int("ZS_GEMM_RING_MIN_TILES", 256);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -791,8 +942,21 @@ extern "C" int zs_gemm_conv(const ZsGemmConv* p, void* stream) {
   ZS_REQUIRE(tiles < (1ll << 31), "zs_gemm_conv: grid too large");
   dim3 grid((unsigned)tiles, 1, (unsigned)groups);
   hipStream_t s = (hipStream_t)stream;
-  static const int use_dma = [] { const char* e = getenv("ZS_GEMM_DMA"); return e ? atoi(e) : 1; }();
-  if (use_dma) {
+  init_options();
+  const int use_dma = g_use_dma, use_ring = g_use_ring;
+  const int64_t ring_tiles = ((M + RBM - 1) / RBM) * ((p->N + BN - 1) / BN);
+  if (use_dma && use_ring && ring_tiles >= g_ring_min_tiles && ring_tiles < (1ll << 31)) {
+    // enough 256x128 tiles to give every CU one workgroup: 3-stage ring kernel
+    dim3 rgrid((unsigned)ring_tiles, 1, (unsigned)groups);
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_ring_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_ring_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);
+      attr_set = true;
+    }
+    if (p->dtype == ZS_F32) hipLaunchKernelGGL(gemm_conv_ring_kernel<float>, rgrid, dim3(RNT), RING_LDS, s, *p);
+    else hipLaunchKernelGGL(gemm_conv_ring_kernel<bf16_t>, rgrid, dim3(RNT), RING_LDS, s, *p);
+  } else if (use_dma) {
     const size_t lds = (4 * DTILE > EPI_LDS_BYTES) ? 4 * DTILE : EPI_LDS_BYTES;
     if (p->dtype == ZS_F32) hipLaunchKernelGGL(gemm_conv_dma_kernel<float>, grid, dim3(NT), lds, s, *p);
     else hipLaunchKernelGGL(gemm_conv_dma_kernel<bf16_t>, grid, dim3(NT), lds, s, *p);
@@ -802,6 +966,18 @@ extern "C" int zs_gemm_conv(const ZsGemmConv* p, void* stream) {
     else hipLaunchKernelGGL(gemm_conv_kernel<bf16_t>, grid, dim3(NT), lds, s, *p);
   }
   return zs_check_launch("zs_gemm_conv");
+}
+
+extern "C" int zs_set_option(const char* key, int value) {
+  init_options();
+  int* slot = nullptr;
+  if (key && !strcmp(key, "gemm_dma")) slot = &g_use_dma;
+  else if (key && !strcmp(key, "gemm_ring")) slot = &g_use_ring;
+  else if (key && !strcmp(key, "gemm_ring_min_tiles")) slot = &g_ring_min_tiles;
+  if (!slot) { zs_set_error("zs_set_option: unknown key %s", key ? key : "(null)"); return ZS_EINVAL; }
+  const int old = *slot;
+  *slot = value;
+  return old;
 }
 
 extern "C" size_t zs_gemm_wgrad_workspace_bytes(const ZsGemmWgrad* p) {
