@@ -240,7 +240,7 @@ def main():
         fl, ms, n = ke.summary()
         ach = fl / (ms * 1e-3) / 1e12
         out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic, 'traffic_unit': 'bytes/launch',
-                           'kernel': 'gemm_conv_dma_kernel<%s>' % ('bf16' if args.dtype == 'bf16' else 'float'),
+                           'kernel': 'zs_gemm_conv launches (gemm_conv_p8/ring/dma_kernel<%s>)' % ('bf16' if args.dtype == 'bf16' else 'float'),
                            'launches_timed': n, 'avg_launch_ms': ms / n, 'avg_launch_gflop': fl / n / 1e9,
                            'measured_on': ('instrumented eager steps after the timed region' if ae.use_graph else 'the timed steps')}
     else:

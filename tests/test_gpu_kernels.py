@@ -75,14 +75,22 @@ def _ref_conv(x_btc, w, b, stride, reflect):
     return F.conv1d(xp, w3, b, stride=stride).permute(0, 2, 1)
 
 
-@pytest.fixture(params=['ring', 'dma', 'reg'])
+GEMM_KEYS = ('gemm_dma', 'gemm_ring', 'gemm_ring_min_tiles', 'gemm_pp', 'gemm_p8', 'gemm_p8_min_tiles', 'wgrad_p8')
+GEMM_VARIANTS = {'p8': (1, 1, 1, 1, 1, 1, 2), 'pp': (1, 1, 1, 1, 0, 200, 0), 'ring': (1, 1, 1, 0, 0, 200, 0),
+                 'dma': (1, 0, 256, 0, 0, 200, 0), 'reg': (0, 0, 256, 0, 0, 200, 0)}
+
+
+@pytest.fixture(params=list(GEMM_VARIANTS))
 def gemm_variant(request, zs):
-    """Run a test with each of the three conv-GEMM kernels: 256x128 3-stage ring, 128x128 LDS-DMA, 128x128 register-staged."""
+    """Run a test with each conv-GEMM kernel: 256x256 quadrant ping-pong (where the packed weight has a multiple of 256 rows,
+    else it falls through to the ring), 256x128 3-stage ring with the ping-pong schedule, the same ring in lock-step,
+    128x128 LDS-DMA, 128x128 register-staged.  The 'p8' variant also forces the 256x256 ping-pong weight-gradient kernel
+    (bf16; wgrad_p8=2 overrides its size heuristics), the others use the 128x128 one."""
     L, _ = zs
-    want = {'ring': (1, 1, 1), 'dma': (1, 0, 256), 'reg': (0, 0, 256)}[request.param]
-    old = (L.set_option('gemm_dma', want[0]), L.set_option('gemm_ring', want[1]), L.set_option('gemm_ring_min_tiles', want[2]))
+    old = [L.set_option(k, v) for k, v in zip(GEMM_KEYS, GEMM_VARIANTS[request.param])]
     yield request.param
-    L.set_option('gemm_dma', old[0]); L.set_option('gemm_ring', old[1]); L.set_option('gemm_ring_min_tiles', old[2])
+    for k, v in zip(GEMM_KEYS, old):
+        L.set_option(k, v)
 
 
 CONV_CASES = [
@@ -91,6 +99,7 @@ CONV_CASES = [
     (2, 24, 80, 16, 5, 1, True), (2, 24, 80, 16, 6, 1, True), (2, 24, 80, 16, 7, 1, True),
     (3, 50, 513, 130, 7, 1, True), (2, 9, 32, 32, 5, 2, True), (2, 33, 64, 48, 5, 2, True), (5, 64, 96, 513, 1, 1, True),
     (2, 20, 32, 40, 3, 1, False), (2, 21, 32, 40, 5, 2, False), (1, 300, 160, 256, 3, 1, True), (3, 200, 64, 200, 3, 1, True),
+    (4, 130, 192, 512, 3, 1, True), (3, 90, 136, 250, 5, 2, False),
 ]
 
 
@@ -148,7 +157,7 @@ def test_conv_epilogue_split2_vec(zs, dtype, gemm_variant):
 
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('case', [(2, 16, 32, 48, 5, 1), (2, 16, 32, 48, 5, 2), (3, 12, 64, 32, 3, 1), (2, 10, 40, 24, 1, 1),
-                                  (2, 128, 96, 80, 5, 2)])
+                                  (2, 128, 96, 80, 5, 2), (4, 200, 300, 520, 3, 1), (3, 130, 136, 250, 1, 1)])
 def test_conv_backward(zs, dtype, case, gemm_variant):
     """dgrad (padded domain) + reflect fold + lrelu' ; wgrad ; bias grad -- against autograd."""
     L, layers = zs
@@ -178,7 +187,7 @@ def test_conv_backward(zs, dtype, case, gemm_variant):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-def test_wgrad_split2_and_shift(zs, dtype):
+def test_wgrad_split2_and_shift(zs, dtype, gemm_variant):
     L, layers = zs
     B, T, Cin, C = 2, 12, 32, 16
     g = torch.Generator().manual_seed(5)

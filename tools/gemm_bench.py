@@ -16,17 +16,34 @@ ap.add_argument('--B', type=int, default=256); ap.add_argument('--T', type=int, 
 ap.add_argument('--cin', type=int, default=1024); ap.add_argument('--cout', type=int, default=2048)
 ap.add_argument('--k', type=int, default=3); ap.add_argument('--dtype', default='bf16')
 ap.add_argument('--iters', type=int, default=20); ap.add_argument('--mode', default='fwd')
+ap.add_argument('--variants', default='p8,pp,dma')
+ap.add_argument('--fill', default='normal', help='normal | zeros | ones: operand values (MFMA power depends on bit toggling)')
 a = ap.parse_args()
+os.environ['ZS_OVERLAP_WGRAD'] = '0'      # time the weight gradient on the stream the events are recorded on
 ctx = layers.Ctx('cuda:0', a.dtype)
 dev = ctx.device
 w = torch.randn(a.cout, a.cin, a.k, device=dev) * 0.02
+if a.fill in ('zeros', 'ones'):
+    w.fill_(0.0 if a.fill == 'zeros' else 1.0)
+elif a.fill == 'uniform':
+    w.uniform_(-1, 1)
 b = torch.zeros(a.cout, device=dev)
 l = layers.ConvLayer(ctx, w, b, torch.zeros_like(w), torch.zeros_like(b))
 l.pack()
 X = ctx.act('x', a.B, a.T, a.cin)
 X.t.normal_()
+if a.fill in ('zeros', 'ones'):
+    X.t.fill_(0.0 if a.fill == 'zeros' else 1.0)
+elif a.fill == 'uniform':
+    X.t.uniform_(-1, 1)
+elif a.fill == 'lrelu':
+    X.t.copy_(torch.nn.functional.leaky_relu(X.t.float(), 0.01))
+elif a.fill == 'drop':
+    X.t.mul_((torch.rand(X.t.shape, device=dev) < 0.5).to(X.t.dtype) * 2)
 Y = ctx.act('y', a.B, a.T, a.cout)
 Y.t.normal_()
+if a.fill in ('zeros', 'ones'):
+    Y.t.fill_(0.0 if a.fill == 'zeros' else 1.0)
 GP = ctx.act('gp', a.B, a.T + l.pad_l + l.pad_r, a.cin)
 
 
@@ -39,15 +56,26 @@ def run():
         l.wgrad(Y, X)
 
 
-for _ in range(3):
-    run()
-torch.cuda.synchronize()
-s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-s.record()
-for _ in range(a.iters):
-    run()
-e.record()
-torch.cuda.synchronize()
-ms = s.elapsed_time(e) / a.iters
+def timed():
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(a.iters):
+        run()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / a.iters
+
+
 fl = 2.0 * a.B * a.T * a.cout * a.cin * a.k
-print('%s %s B%d T%d cin%d cout%d k%d: %.3f ms  %.1f TFLOP/s' % (a.mode, a.dtype, a.B, a.T, a.cin, a.cout, a.k, ms, fl / ms / 1e9))
+VARIANTS = {'p8': (1, 1, 1, 1, 1, 1), 'pp': (1, 1, 1, 1, 0, 200), 'ring': (1, 1, 1, 0, 0, 200), 'dma': (1, 0, 256, 0, 0, 200), 'reg': (0, 0, 256, 0, 0, 200)}
+for name in (a.variants.split(',') if a.mode != 'wgrad' else ['p8', 't128']):
+    if a.mode == 'wgrad':
+        L.set_option('wgrad_p8', 1 if name == 'p8' else 0)
+    else:
+        for k, v in zip(('gemm_dma', 'gemm_ring', 'gemm_ring_min_tiles', 'gemm_pp', 'gemm_p8', 'gemm_p8_min_tiles'), VARIANTS[name]):
+            L.set_option(k, v)
+    ms = timed()
+    print('%s %s %-4s %s B%d T%d cin%d cout%d k%d: %.3f ms  %.1f TFLOP/s' % (a.mode, a.dtype, name, a.fill, a.B, a.T, a.cin, a.cout, a.k, ms, fl / ms / 1e9), flush=True)

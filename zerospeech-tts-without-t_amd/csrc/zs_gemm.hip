@@ -90,9 +90,11 @@ __device__ __forceinline__ void store_group(OT* base, int64_t row, int64_t ld, i
 }
 
 template <typename T, int NTHREADS>
+__device__ __forceinline__ void epilogue_finish(const ZsGemmConv& p, const float* sC, int M, int m0, int n0, int tid, int g);
+
+template <typename T, int NTHREADS>
 __device__ __forceinline__ void gemm_epilogue(const ZsGemmConv& p, f32x16 (&acc)[2][2], float* sC, int M, int m0, int n0,
                                               int wm, int wn, int tid, int g) {
-  constexpr int ROWS_PER_PASS = NTHREADS / 16;      // 128-row tile with 256 threads, 256-row tile with 512: 8 passes
   const int lane = tid & 63;
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
@@ -105,7 +107,13 @@ __device__ __forceinline__ void gemm_epilogue(const ZsGemmConv& p, f32x16 (&acc)
         sC[row * CPITCH + col] = acc[mi][ni][r];
       }
   __syncthreads();
+  epilogue_finish<T, NTHREADS>(p, sC, M, m0, n0, tid, g);
+}
 
+// finishes the staged [NTHREADS/2 rows][128 columns] fp32 tile at (m0, n0)
+template <typename T, int NTHREADS>
+__device__ __forceinline__ void epilogue_finish(const ZsGemmConv& p, const float* sC, int M, int m0, int n0, int tid, int g) {
+  constexpr int ROWS_PER_PASS = NTHREADS / 16;      // 128-row tile with 256 threads, 256-row tile with 512: 8 passes
   const int cg = tid & 15, rr0 = tid >> 4;          // 16 column groups x 16 rows per pass, 8 passes
   const int n = n0 + cg * 8;
   if (n >= p.N && n >= p.out_cols && n >= p.out2_cols) return;
@@ -518,12 +526,12 @@ constexpr int RSTAGE = (RBM + BN) * 128;          // 49,152 B
 constexpr int RING_LDS = 3 * RSTAGE;              // 147,456 B  (>= epilogue staging 256*132*4 = 135,168 B)
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
-template <typename T>
+template <typename T, int PP>
 __global__ __launch_bounds__(RNT, 2) void gemm_conv_ring_kernel(const ZsGemmConv p) {
   constexpr int EPS = 16 / (int)sizeof(T);
   constexpr int KC = ROWB / (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int g = blockIdx.z;
   const T* __restrict__ A = (const T*)p.A + (int64_t)g * p.a_gstride;
@@ -568,15 +576,19 @@ __global__ __launch_bounds__(RNT, 2) void gemm_conv_ring_kernel(const ZsGemmConv
   { ZS_SET_TAP(0, pa0, inc0) ZS_SET_TAP(1, pa1, inc1) ZS_SET_TAP(2, pa2, inc2) ZS_SET_TAP(3, pa3, inc3) }
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  auto dma = [&](int stage) {
+  // one 1-KiB LDS-DMA piece of the next chunk: i = 0..3 A rows, 4..5 W rows.  Pieces are issued BETWEEN the MFMA groups:
+  // an LDS-DMA issued in a phase that also carries ds_read_b128 costs the issuing wave 100-185 cycles, ~60 among MFMAs
+  auto dma_piece = [&](int stage, int i) {
     unsigned char* da = smem + stage * RSTAGE + wave * 4096;               // A rows wave*32 ..
     unsigned char* db = smem + stage * RSTAGE + RBM * 128 + wave * 2048;   // W rows wave*16 ..
-    __builtin_amdgcn_global_load_lds((gptr_t)pa0, (lptr_t)(da), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)pa1, (lptr_t)(da + 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)pa2, (lptr_t)(da + 2048), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)pa3, (lptr_t)(da + 3072), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)pw0, (lptr_t)(db), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)pw1, (lptr_t)(db + 1024), 16, 0, 0);
+    if (i == 0) __builtin_amdgcn_global_load_lds((gptr_t)pa0, (lptr_t)(da), 16, 0, 0);
+    else if (i == 1) __builtin_amdgcn_global_load_lds((gptr_t)pa1, (lptr_t)(da + 1024), 16, 0, 0);
+    else if (i == 2) __builtin_amdgcn_global_load_lds((gptr_t)pa2, (lptr_t)(da + 2048), 16, 0, 0);
+    else if (i == 3) __builtin_amdgcn_global_load_lds((gptr_t)pa3, (lptr_t)(da + 3072), 16, 0, 0);
+    else if (i == 4) __builtin_amdgcn_global_load_lds((gptr_t)pw0, (lptr_t)(db), 16, 0, 0);
+    else __builtin_amdgcn_global_load_lds((gptr_t)pw1, (lptr_t)(db + 1024), 16, 0, 0);
+  };
+  auto dma_advance = [&]() {
     pw0 += KC; pw1 += KC;
     if (++cit == chunks_per_tap) {
       cit = 0; ++tap;
@@ -584,6 +596,11 @@ __global__ __launch_bounds__(RNT, 2) void gemm_conv_ring_kernel(const ZsGemmConv
     } else {
       pa0 += inc0; pa1 += inc1; pa2 += inc2; pa3 += inc3;
     }
+  };
+  auto dma = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dma_piece(stage, i);
+    dma_advance();
   };
 #undef ZS_SET_TAP
 
@@ -604,6 +621,77 @@ __global__ __launch_bounds__(RNT, 2) void gemm_conv_ring_kernel(const ZsGemmConv
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) koff[ks] = (unsigned)(((2 * ks + fh) ^ fx) * 16);
 
+  if constexpr (PP) {
+    // Ping-pong schedule: waves 0-3 (group 0) and 4-7 (group 1) share the four SIMDs pairwise and run ONE barrier apart, with
+    // two barriers per chunk, so that in every barrier interval one group of a SIMD reads fragments (L) while the other runs
+    // its 16 MFMAs (M):
+    //   group 0:      L0 | M0 | L1 | M1 | ...        L_k: 16 ds_read(chunk k) [+ g0: DMA chunk k+2]; lgkmcnt(0); [g1: vmcnt]
+    //   group 1:   -  |  L0 | M0 | L1 | M1 ...       M_k: 16 MFMA [+ g1: DMA chunk k+3 between them]; [g0: vmcnt]
+    // A chunk is read only after every wave waited for its own DMA pieces of it and a barrier followed (RAW); a stage is
+    // refilled only after both groups' lgkmcnt(0) of the chunk it held and a barrier (WAR).
+    const int grp1 = wave >> 2;
+    dma(0);
+    if (nk > 1) dma(1);
+    if (grp1 && nk > 2) dma(2);
+    {
+      const int fly = (grp1 ? min(nk, 3) : min(nk, 2)) - 1;      // chunks that may still be in flight
+      if (fly == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (fly == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (grp1) __builtin_amdgcn_s_barrier();
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const unsigned sa = a_lane + (unsigned)(stage * RSTAGE), sb = b_lane + (unsigned)(stage * RSTAGE);
+      u32x4_t fa[4][2], fb[4][2];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fa[ks][0]) : "v"(sa + koff[ks]));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fa[ks][1]) : "v"(sa + koff[ks]));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fb[ks][0]) : "v"(sb + koff[ks]));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fb[ks][1]) : "v"(sb + koff[ks]));
+      }
+      int s2 = stage + 2; if (s2 >= 3) s2 -= 3;
+      if (!grp1 && kt + 2 < nk) dma(s2);                          // group 0: chunk kt+2 -> stage (kt+2)%3
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (grp1) {                                                 // group 1: its pieces of chunk kt+1 have landed
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const bool more1 = grp1 && (kt + 3 < nk);                   // group 1: chunk kt+3 -> stage kt%3 (read by everyone already)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const uint4 ua = make_uint4(fa[ks][mi].x, fa[ks][mi].y, fa[ks][mi].z, fa[ks][mi].w);
+            const uint4 ub = make_uint4(fb[ks][ni].x, fb[ks][ni].y, fb[ks][ni].z, fb[ks][ni].w);
+            Mma<T>::run(ua, ub, acc[mi][ni]);
+          }
+        if (more1 && ks < 3) {
+          __builtin_amdgcn_sched_barrier(0);
+          dma_piece(stage, 2 * ks);
+          dma_piece(stage, 2 * ks + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if (more1) dma_advance();
+      if (!grp1) {                                                // group 0: its pieces of chunk kt+1 have landed
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (++stage == 3) stage = 0;
+    }
+    if (!grp1) __builtin_amdgcn_s_barrier();                      // pairs with group 1's last barrier
+  } else {
   dma(0);
   if (nk > 1) dma(1);
   int stage = 0;
@@ -620,14 +708,12 @@ __global__ __launch_bounds__(RNT, 2) void gemm_conv_ring_kernel(const ZsGemmConv
       asm volatile("ds_read_b128 %0, %1" : "=v"(fb[ks][0]) : "v"(sb + koff[ks]));
       asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fb[ks][1]) : "v"(sb + koff[ks]));
     }
-    if (kt + 2 < nk) {
-      int s2 = stage + 2; if (s2 >= 3) s2 -= 3;
-      dma(s2);                                   // stage (kt+2)%3 == (kt-1)%3: everybody finished reading it before the barrier
-    }
+    const bool more = kt + 2 < nk;                 // chunk kt+2 -> stage (kt+2)%3 == (kt-1)%3: nobody reads it any more
+    int s2 = stage + 2; if (s2 >= 3) s2 -= 3;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);            // MFMAs (register-only) must stay below the wait
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -636,12 +722,242 @@ __global__ __launch_bounds__(RNT, 2) void gemm_conv_ring_kernel(const ZsGemmConv
           const uint4 ub = make_uint4(fb[ks][ni].x, fb[ks][ni].y, fb[ks][ni].z, fb[ks][ni].w);
           Mma<T>::run(ua, ub, acc[mi][ni]);
         }
+      if (more && ks < 3) {                        // two DMA pieces behind each of the first three MFMA groups
+        __builtin_amdgcn_sched_barrier(0);
+        dma_piece(s2, 2 * ks);
+        dma_piece(s2, 2 * ks + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (more) dma_advance();
     __builtin_amdgcn_sched_barrier(0);
     if (++stage == 3) stage = 0;
+  }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                // all fragment reads done before the ring is reused as the staging tile
   gemm_epilogue<T, RNT>(p, acc, reinterpret_cast<float*>(smem), M, m0, n0, wm, wn, tid, g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 256x256 "quadrant ping-pong" kernel for the large layers.  A power-capped MI355X (1400 W: the 128x128 / 256x128 kernels
+// above already draw 1350 W at 0.9 PFLOP/s, sclk 2.03 GHz) is faster only with fewer bytes moved per FLOP, so:
+//   * 256x256 tile, 8 waves as 2(M) x 4(N), each 128x64 = 2x2 quadrants of 64x32 (two 32x32x16 MFMA tiles x 4 k-steps):
+//     1/128 operand byte from L2 per FLOP (256x128: 3/256) and 3/128 fragment bytes from LDS per FLOP per wave (64x64: 4/128).
+//   * K tile = 128 B per row, 64 KiB per stage (A 256 rows | W 256 rows), TWO stages, each split in four 16-KiB half-tiles
+//     (A0 A1 B0 B1) that are refilled by LDS-DMA as soon as their last reader is done:
+//        during tile k (stage s):  phase 1: A0(k+1) -> s^1   phase 2: A1(k+1) -> s^1   phase 3: B0(k+2) -> s   phase 4: B1(k+2) -> s
+//     (every wave issues 2 pieces per phase, between its MFMAs), so 3 half-tiles stay in flight across the barriers.
+//   * Four phases per K tile, one quadrant each:  (0,0) reads A[mq0] (8 ds_read_b128) + B[nq0] (4) | (0,1) reads B[nq1] (4) |
+//     (1,1) reads A[mq1] (8) | (1,0) reads nothing.  Phase = L (fragment reads, lgkmcnt(0)) ; s_barrier ; M (8 MFMA + 2 DMA
+//     pieces) ; s_barrier.  Waves 0-3 (M half 0) and 4-7 (M half 1) share the SIMDs pairwise and run ONE barrier apart, so on
+//     every SIMD one wave is in M while the other is in L.
+//   * One counted wait per K tile: group 0 at the end of M4 (vmcnt 4: only B0/B1(k+2) may fly), group 1 at the end of its L4
+//     (vmcnt 2: it has not issued B1(k+2) yet); both sit before the barrier that precedes the first read of tile k+1.
+//     WAR: a half-tile is refilled at least one barrier after the lgkmcnt(0) of its last reader (A halves are read by one
+//     group only: phases 1 and 3; B halves by both: phases 1 and 2).
+// ------------------------------------------------------------------------------------------------
+constexpr int PBM = 256, PBN = 256, PNT = 512;
+constexpr int PSTAGE = (PBM + PBN) * 128;                     // 65,536 B
+constexpr int P8_EPI = 256 * CPITCH * 4;                      // 135,168 B: staging of a 256 x 128 fp32 half
+constexpr int P8_LDS = (2 * PSTAGE > P8_EPI) ? 2 * PSTAGE : P8_EPI;
+
+#define ZS_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+#define ZS_P8_READ_A(o0, o1)                                                     \
+  ZS_DSR(fa00, sa + koff0, o0); ZS_DSR(fa01, sa + koff0, o1); ZS_DSR(fa10, sa + koff1, o0); ZS_DSR(fa11, sa + koff1, o1); \
+  ZS_DSR(fa20, sa + koff2, o0); ZS_DSR(fa21, sa + koff2, o1); ZS_DSR(fa30, sa + koff3, o0); ZS_DSR(fa31, sa + koff3, o1);
+#define ZS_P8_READ_B(f0, f1, f2, f3, o)                                          \
+  ZS_DSR(f0, sb + koff0, o); ZS_DSR(f1, sb + koff1, o); ZS_DSR(f2, sb + koff2, o); ZS_DSR(f3, sb + koff3, o);
+#define ZS_P8_MMA(a, b, c) Mma<T>::run(make_uint4(a.x, a.y, a.z, a.w), make_uint4(b.x, b.y, b.z, b.w), c)
+#define ZS_P8_DMA(cond, src, dst)                                                \
+  __builtin_amdgcn_sched_barrier(0);                                             \
+  if (cond) __builtin_amdgcn_global_load_lds((gptr_t)(src), (lptr_t)(dst), 16, 0, 0); \
+  __builtin_amdgcn_sched_barrier(0);
+// one quadrant: 8 MFMAs (k-step major, the two 32-row tiles alternate) with two DMA pieces between them
+#define ZS_P8_QUAD(c0, c1, b0, b1, b2, b3, cond, src0, dst0, src1, dst1)         \
+  __builtin_amdgcn_s_setprio(1);                                                 \
+  ZS_P8_MMA(fa00, b0, c0); ZS_P8_MMA(fa01, b0, c1);                              \
+  ZS_P8_DMA(cond, src0, dst0)                                                    \
+  ZS_P8_MMA(fa10, b1, c0); ZS_P8_MMA(fa11, b1, c1); ZS_P8_MMA(fa20, b2, c0);     \
+  ZS_P8_DMA(cond, src1, dst1)                                                    \
+  ZS_P8_MMA(fa21, b2, c1); ZS_P8_MMA(fa30, b3, c0); ZS_P8_MMA(fa31, b3, c1);     \
+  __builtin_amdgcn_s_setprio(0);
+
+template <typename T>
+__global__ __launch_bounds__(PNT, 2) void gemm_conv_p8_kernel(const ZsGemmConv p) {
+  constexpr int EPS = 16 / (int)sizeof(T);
+  constexpr int KC = ROWB / (int)sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int g = blockIdx.z;
+  const T* __restrict__ A = (const T*)p.A + (int64_t)g * p.a_gstride;
+  const T* __restrict__ W = (const T*)p.W + (int64_t)g * p.w_gstride;
+  const int M = p.B * p.T_out;
+  const int ntn = (p.N + PBN - 1) / PBN;
+  const int ntm = (M + PBM - 1) / PBM;
+  const int wg = xcd_remap(blockIdx.x, ntm * ntn);
+  constexpr int GM = 4;
+  const int per_group = GM * ntn;
+  const int grp = wg / per_group;
+  const int gm = min(GM, ntm - grp * GM);
+  const int in_g = wg - grp * per_group;
+  const int m0 = (grp * GM + in_g % gm) * PBM, n0 = (in_g / gm) * PBN;
+
+  // loader: piece j = 0..3 of a K tile covers rows (j>>1)*128 + wave*16 + (j&1)*8 + lane/8 of A and of W
+  const int lrow = lane >> 3, slot = lane & 7;
+  int rb[4], rt[4], lseg[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = (j >> 1) * 128 + wave * 16 + (j & 1) * 8 + lrow;
+    lseg[j] = slot ^ ((r >> 1) & 7);
+    const int m = m0 + r;
+    if (m < M) { rb[j] = m / p.T_out; rt[j] = m - rb[j] * p.T_out; } else { rb[j] = -1; rt[j] = 0; }
+  }
+  const int chunks_per_tap = p.cin_pad / KC;
+  const T* zline = reinterpret_cast<const T*>(zs_zero_line);
+  const T *pa0, *pa1, *pa2, *pa3;
+  int inc0, inc1, inc2, inc3;
+#define ZS_SET_TAP(i, ptr, inc)                                                                         \
+  {                                                                                                     \
+    bool ok = false; int srow = 0;                                                                      \
+    if (rb[i] >= 0) srow = conv_src_row(p.gather, p.pad_mode, p.stride, p.pad_left, p.T_in, rt[i], tap, ok); \
+    ptr = ok ? (A + (int64_t)rb[i] * p.a_batch_stride + (int64_t)srow * p.lda + lseg[i] * EPS) : (zline + lseg[i] * EPS); \
+    inc = ok ? KC : 0;                                                                                  \
+  }
+  const int nk = p.taps * chunks_per_tap;
+  int tap = 0, cit = 0;
+  { ZS_SET_TAP(0, pa0, inc0) ZS_SET_TAP(1, pa1, inc1) ZS_SET_TAP(2, pa2, inc2) ZS_SET_TAP(3, pa3, inc3) }
+  auto advance_a = [&]() {
+    if (++cit == chunks_per_tap) {
+      cit = 0; ++tap;
+      if (tap < p.taps) { ZS_SET_TAP(0, pa0, inc0) ZS_SET_TAP(1, pa1, inc1) ZS_SET_TAP(2, pa2, inc2) ZS_SET_TAP(3, pa3, inc3) }
+    } else {
+      pa0 += inc0; pa1 += inc1; pa2 += inc2; pa3 += inc3;
+    }
+  };
+#undef ZS_SET_TAP
+  // W rows n0 + r_j (the packed matrix has n_pad >= n0 + 256 rows: checked on the host)
+  const T* pw0 = W + (int64_t)(n0 + wave * 16 + lrow) * p.ldw + lseg[0] * EPS;
+  const T* pw1 = W + (int64_t)(n0 + wave * 16 + 8 + lrow) * p.ldw + lseg[1] * EPS;
+  const int64_t whalf = (int64_t)128 * p.ldw;                 // rows +128: pieces 2, 3
+
+  unsigned char* const ldsA = smem + wave * 2048;             // + stage*PSTAGE + (j>>1)*16384 + (j&1)*1024
+  unsigned char* const ldsB = smem + 32768 + wave * 2048;
+
+  f32x16 c000, c001, c010, c011, c100, c101, c110, c111;     // c[mq][nq][mi]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { c000[r] = 0.f; c001[r] = 0.f; c010[r] = 0.f; c011[r] = 0.f; c100[r] = 0.f; c101[r] = 0.f; c110[r] = 0.f; c111[r] = 0.f; }
+
+  // fragment addresses: A row = wr*128 + mq*64 + mi*32 + (lane&31), W row = wc*64 + nq*32 + (lane&31); slot = (2ks + lane>>5) ^ ((row>>1)&7)
+  const int frow = lane & 31, fh = lane >> 5, fx = (frow >> 1) & 7;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned a_lane = lds0 + (unsigned)((wr * 128 + frow) * 128);
+  const unsigned b_lane = lds0 + (unsigned)(32768 + (wc * 64 + frow) * 128);
+  const unsigned koff0 = (unsigned)(((0 + fh) ^ fx) * 16), koff1 = (unsigned)(((2 + fh) ^ fx) * 16);
+  const unsigned koff2 = (unsigned)(((4 + fh) ^ fx) * 16), koff3 = (unsigned)(((6 + fh) ^ fx) * 16);
+  const int grp1 = wr;
+
+  // prologue: A(0) B(0) -> stage 0, B(1) -> stage 1
+  __builtin_amdgcn_global_load_lds((gptr_t)pa0, (lptr_t)(ldsA), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((gptr_t)pa1, (lptr_t)(ldsA + 1024), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((gptr_t)pa2, (lptr_t)(ldsA + 16384), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((gptr_t)pa3, (lptr_t)(ldsA + 16384 + 1024), 16, 0, 0);
+  advance_a();
+  __builtin_amdgcn_global_load_lds((gptr_t)pw0, (lptr_t)(ldsB), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((gptr_t)pw1, (lptr_t)(ldsB + 1024), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((gptr_t)(pw0 + whalf), (lptr_t)(ldsB + 16384), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((gptr_t)(pw1 + whalf), (lptr_t)(ldsB + 16384 + 1024), 16, 0, 0);
+  pw0 += KC; pw1 += KC;
+  if (nk > 1) {
+    __builtin_amdgcn_global_load_lds((gptr_t)pw0, (lptr_t)(ldsB + PSTAGE), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)pw1, (lptr_t)(ldsB + PSTAGE + 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(pw0 + whalf), (lptr_t)(ldsB + PSTAGE + 16384), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(pw1 + whalf), (lptr_t)(ldsB + PSTAGE + 16384 + 1024), 16, 0, 0);
+    pw0 += KC; pw1 += KC;
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (grp1) __builtin_amdgcn_s_barrier();
+
+  u32x4_t fa00, fa01, fa10, fa11, fa20, fa21, fa30, fa31;    // fa[ks][mi]
+  u32x4_t fb00, fb01, fb02, fb03, fb10, fb11, fb12, fb13;    // fb[nq][ks]
+  for (int kt = 0; kt < nk; ++kt) {
+    const int st = kt & 1;
+    const unsigned sa = a_lane + (unsigned)(st * PSTAGE), sb = b_lane + (unsigned)(st * PSTAGE);
+    const bool has_a = kt + 1 < nk, has_b = kt + 2 < nk;
+    unsigned char* const dA = ldsA + (st ^ 1) * PSTAGE;
+    unsigned char* const dB = ldsB + st * PSTAGE;
+    // ---- phase 1: quadrant (0,0); A0(kt+1)
+    ZS_P8_READ_A(0, 4096)
+    ZS_P8_READ_B(fb00, fb01, fb02, fb03, 0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    ZS_P8_QUAD(c000, c001, fb00, fb01, fb02, fb03, has_a, pa0, dA, pa1, dA + 1024)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 2: quadrant (0,1); A1(kt+1)
+    ZS_P8_READ_B(fb10, fb11, fb12, fb13, 4096)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    ZS_P8_QUAD(c010, c011, fb10, fb11, fb12, fb13, has_a, pa2, dA + 16384, pa3, dA + 16384 + 1024)
+    if (has_a) advance_a();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 3: quadrant (1,1); B0(kt+2)
+    ZS_P8_READ_A(8192, 12288)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    ZS_P8_QUAD(c110, c111, fb10, fb11, fb12, fb13, has_b, pw0, dB, pw1, dB + 1024)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 4: quadrant (1,0); B1(kt+2); the counted waits for tile kt+1
+    if (grp1) {
+      if (has_b) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    ZS_P8_QUAD(c100, c101, fb00, fb01, fb02, fb03, has_b, pw0 + whalf, dB + 16384, pw1 + whalf, dB + 16384 + 1024)
+    if (has_b) { pw0 += KC; pw1 += KC; }
+    if (!grp1) {
+      if (has_b) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (!grp1) __builtin_amdgcn_s_barrier();          // pairs with group 1's last barrier
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // epilogue in two 128-column halves through the [256][132] fp32 staging tile
+  float* sC = reinterpret_cast<float*>(smem);
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    if ((wc >> 1) == h) {
+      const int cb = (wc & 1) * 64 + (lane & 31);
+      const int rbase = wr * 128 + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ro = (r & 3) + 8 * (r >> 2);
+        sC[(rbase + ro) * CPITCH + cb] = c000[r];            sC[(rbase + 32 + ro) * CPITCH + cb] = c001[r];
+        sC[(rbase + ro) * CPITCH + cb + 32] = c010[r];       sC[(rbase + 32 + ro) * CPITCH + cb + 32] = c011[r];
+        sC[(rbase + 64 + ro) * CPITCH + cb] = c100[r];       sC[(rbase + 96 + ro) * CPITCH + cb] = c101[r];
+        sC[(rbase + 64 + ro) * CPITCH + cb + 32] = c110[r];  sC[(rbase + 96 + ro) * CPITCH + cb + 32] = c111[r];
+      }
+    }
+    __syncthreads();
+    epilogue_finish<T, PNT>(p, sC, M, m0, n0 + h * 128, tid, g);
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -866,6 +1182,261 @@ __global__ __launch_bounds__(NT, 2) void gemm_wgrad_kernel(const ZsGemmWgrad p, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 weight gradient on the quadrant ping-pong schedule of gemm_conv_p8_kernel (same regions, phases, DMA order and
+// waits; read that comment first).  Tile = 256 co x 256 ci of one tap, K tile = 64 rows m.  Both operands are K(=row)-major
+// in memory, so an LDS "row" is (64-channel block cb, row k): 128 B = 64 channels of dY (or gathered X) row k; the A region
+// holds co blocks 0..3 (half-tiles A0 = blocks 0,1, A1 = 2,3), the B region ci blocks 0..3.  A 1-KiB DMA piece is 8 rows k
+// of one channel block, so global reads stay 128 B contiguous per row, exactly as in the conv kernels.
+// Fragments come from the transposing read ds_read_b64_tr_b16 (per 16-lane group: lane 4q+p addresses row q, channels
+// 4p..4p+3 of a 4-row x 16-channel block; lane i receives channel i of the 4 rows): two reads per MFMA operand.  Rows are
+// stored with the two 64-byte halves of a row swapped when (k>>1)&1 (done on the DMA source side), so the 4 rows x 64 B a
+// 32-lane half touches fall on 4 distinct 64-byte bank windows.
+// The (tap 0, ci tile 0) workgroup of each co tile also column-sums its dY tiles (bias gradient): 4 extra ds_read_b128
+// per thread and K tile in the light phase 2, reduced through LDS at the end.
+// ------------------------------------------------------------------------------------------------
+#define ZS_DSRT(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+#define ZS_WP_READ_A(base)                                                                        \
+  ZS_DSRT(ya00, sa0, base + 0);    ZS_DSRT(yb00, sa0, base + 512);  ZS_DSRT(ya01, sa1, base + 0);    ZS_DSRT(yb01, sa1, base + 512);  \
+  ZS_DSRT(ya10, sa0, base + 2048); ZS_DSRT(yb10, sa0, base + 2560); ZS_DSRT(ya11, sa1, base + 2048); ZS_DSRT(yb11, sa1, base + 2560); \
+  ZS_DSRT(ya20, sa0, base + 4096); ZS_DSRT(yb20, sa0, base + 4608); ZS_DSRT(ya21, sa1, base + 4096); ZS_DSRT(yb21, sa1, base + 4608); \
+  ZS_DSRT(ya30, sa0, base + 6144); ZS_DSRT(yb30, sa0, base + 6656); ZS_DSRT(ya31, sa1, base + 6144); ZS_DSRT(yb31, sa1, base + 6656);
+#define ZS_WP_READ_B(x, sbx)                                                                      \
+  ZS_DSRT(x##a0, sbx, 0);    ZS_DSRT(x##b0, sbx, 512);  ZS_DSRT(x##a1, sbx, 2048); ZS_DSRT(x##b1, sbx, 2560); \
+  ZS_DSRT(x##a2, sbx, 4096); ZS_DSRT(x##b2, sbx, 4608); ZS_DSRT(x##a3, sbx, 6144); ZS_DSRT(x##b3, sbx, 6656);
+#define ZS_WP_MMA(alo, ahi, blo, bhi, c)                                                          \
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, make_uint4(alo.x, alo.y, ahi.x, ahi.y)), \
+                                               __builtin_bit_cast(bf16x8, make_uint4(blo.x, blo.y, bhi.x, bhi.y)), c, 0, 0, 0)
+#define ZS_WP_DMA(cond, src, dst)                                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                                              \
+  if (cond) __builtin_amdgcn_global_load_lds((gptr_t)(src), (lptr_t)(dst), 16, 0, 0);             \
+  __builtin_amdgcn_sched_barrier(0);
+#define ZS_WP_QUAD(c0, c1, x, cond, src0, dst0, src1, dst1)                                        \
+  __builtin_amdgcn_s_setprio(1);                                                                  \
+  ZS_WP_MMA(ya00, yb00, x##a0, x##b0, c0); ZS_WP_MMA(ya01, yb01, x##a0, x##b0, c1);               \
+  ZS_WP_DMA(cond, src0, dst0)                                                                     \
+  ZS_WP_MMA(ya10, yb10, x##a1, x##b1, c0); ZS_WP_MMA(ya11, yb11, x##a1, x##b1, c1); ZS_WP_MMA(ya20, yb20, x##a2, x##b2, c0); \
+  ZS_WP_DMA(cond, src1, dst1)                                                                     \
+  ZS_WP_MMA(ya21, yb21, x##a2, x##b2, c1); ZS_WP_MMA(ya30, yb30, x##a3, x##b3, c0); ZS_WP_MMA(ya31, yb31, x##a3, x##b3, c1); \
+  __builtin_amdgcn_s_setprio(0);
+
+__global__ __launch_bounds__(PNT, 2) void gemm_wgrad_p8_kernel(const ZsGemmWgrad p, int ci_tiles, int rows_per_split,
+                                                              int cout_r, int cin_r) {
+  typedef bf16_t T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int per_co = p.taps * ci_tiles;
+  const int cot = blockIdx.x / per_co;
+  const int rem = blockIdx.x - cot * per_co;
+  const int tap = rem / ci_tiles, cit = rem - tap * ci_tiles;
+  const int co0 = cot * 256, ci0 = cit * 256;
+  const int M = p.B * p.T_out;
+  const int mbeg = blockIdx.y * rows_per_split;
+  const int mend = min(M, mbeg + rows_per_split);
+  const int nk = (mend - mbeg + 63) / 64;
+  const T* __restrict__ dY = (const T*)p.dY;
+  const T* __restrict__ X = (const T*)p.X;
+  const T* zline = reinterpret_cast<const T*>(zs_zero_line);
+
+  // loader: piece j = 0..3 covers LDS rows (j>>1)*128 + wave*16 + (j&1)*8 + lane/8 = (channel block (j>>1)*2 + wave/4, row k)
+  const int lrow = lane >> 3, slot = lane & 7;
+  const int k0 = (wave & 3) * 16 + lrow, k1 = k0 + 8;                       // the two rows k this lane loads (pieces 0,2 / 1,3)
+  const int cbl = wave >> 2;                                                // channel block of pieces 0,1; pieces 2,3: +2
+  const int sg0 = slot ^ (((k0 >> 1) & 1) << 2), sg1 = slot ^ (((k1 >> 1) & 1) << 2);   // source 16-B segment of the 128-B row
+  // column offsets (elements) and validity of the four pieces, per operand
+  const int yc0 = co0 + cbl * 64 + sg0 * 8, yc1 = co0 + cbl * 64 + sg1 * 8;   // pieces 0,1 ; pieces 2,3: +128
+  const int xc0 = ci0 + cbl * 64 + sg0 * 8, xc1 = ci0 + cbl * 64 + sg1 * 8;
+  auto y_ptr = [&](int m, int col) -> const T* {
+    return (m < mend && col < p.y_cols) ? dY + (int64_t)m * p.ldy + col : zline;
+  };
+  auto x_row = [&](int m, bool& ok) -> const T* {                            // gathered source row of output row m for this tap
+    ok = false;
+    if (m >= mend) return zline;
+    const int b = m / p.T_out, t = m - b * p.T_out;
+    const int srow = conv_src_row(0, p.pad_mode, p.stride, p.pad_left, p.T_in, t, tap, ok);
+    return X + (int64_t)b * p.x_batch_stride + (int64_t)srow * p.ldx;
+  };
+
+  unsigned char* const ldsA = smem + wave * 2048;
+  unsigned char* const ldsB = smem + 32768 + wave * 2048;
+
+  f32x16 c000, c001, c010, c011, c100, c101, c110, c111;     // c[mq][nq][mi]: co = wr*128 + mq*64 + mi*32.., ci = wc*64 + nq*32..
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { c000[r] = 0.f; c001[r] = 0.f; c010[r] = 0.f; c011[r] = 0.f; c100[r] = 0.f; c101[r] = 0.f; c110[r] = 0.f; c111[r] = 0.f; }
+
+  // fragment addresses.  16-lane group gi: channels 16*(gi&1).., rows 8*(gi>>1)..; lane 4q+pp in it: row q, channels 4pp..
+  const int gi = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const int sw = ((q >> 1) & 1) << 2;                                         // (k>>1)&1 of every row this lane addresses
+  const int segl = 2 * (gi & 1) + (pp >> 1);                                  // 16-B segment within a 32-channel MFMA tile
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned rowoff = (unsigned)((8 * (gi >> 1) + q) * 128 + (pp & 1) * 8);
+  const unsigned a_l0 = lds0 + (unsigned)(wr * 2 * 64 * 128) + rowoff + (unsigned)(((0 + segl) ^ sw) * 16);   // mi = 0
+  const unsigned a_l1 = lds0 + (unsigned)(wr * 2 * 64 * 128) + rowoff + (unsigned)(((4 + segl) ^ sw) * 16);   // mi = 1
+  const unsigned b_l0 = lds0 + 32768u + (unsigned)(wc * 64 * 128) + rowoff + (unsigned)(((0 + segl) ^ sw) * 16);   // nq = 0
+  const unsigned b_l1 = lds0 + 32768u + (unsigned)(wc * 64 * 128) + rowoff + (unsigned)(((4 + segl) ^ sw) * 16);   // nq = 1
+  const int grp1 = wr;
+
+  // bias gradient (wave-uniform): group wr sums the A half it reads; thread tg: 8 channels (seg16), rows (tg>>4) + 16 i
+  const bool do_bias = (p.db != nullptr) && tap == 0 && cit == 0;
+  const int tg = tid & 255, seg16 = tg & 15, kr0 = tg >> 4;
+  const unsigned bias_addr = lds0 + (unsigned)(((wr * 2 + (seg16 >> 3)) * 64 + kr0) * 128 + (((seg16 & 7) ^ (((kr0 >> 1) & 1) << 2)) * 16));
+  float bsum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+
+  // prologue: A(0) B(0) -> stage 0, B(1) -> stage 1
+  {
+    __builtin_amdgcn_global_load_lds((gptr_t)y_ptr(mbeg + k0, yc0), (lptr_t)(ldsA), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)y_ptr(mbeg + k1, yc1), (lptr_t)(ldsA + 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)y_ptr(mbeg + k0, yc0 + 128), (lptr_t)(ldsA + 16384), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)y_ptr(mbeg + k1, yc1 + 128), (lptr_t)(ldsA + 16384 + 1024), 16, 0, 0);
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      if (tt < nk) {
+        bool ok0, ok1;
+        const T* r0 = x_row(mbeg + tt * 64 + k0, ok0);
+        const T* r1 = x_row(mbeg + tt * 64 + k1, ok1);
+        unsigned char* d = ldsB + tt * PSTAGE;
+        __builtin_amdgcn_global_load_lds((gptr_t)((ok0 && xc0 < p.x_cols) ? r0 + xc0 : zline), (lptr_t)(d), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)((ok1 && xc1 < p.x_cols) ? r1 + xc1 : zline), (lptr_t)(d + 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)((ok0 && xc0 + 128 < p.x_cols) ? r0 + xc0 + 128 : zline), (lptr_t)(d + 16384), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)((ok1 && xc1 + 128 < p.x_cols) ? r1 + xc1 + 128 : zline), (lptr_t)(d + 16384 + 1024), 16, 0, 0);
+      }
+    }
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (grp1) __builtin_amdgcn_s_barrier();
+
+  uint2 ya00, yb00, ya01, yb01, ya10, yb10, ya11, yb11, ya20, yb20, ya21, yb21, ya30, yb30, ya31, yb31;   // y{a,b}[ks][mi]: rows +0..3 / +4..7
+  uint2 f0a0, f0b0, f0a1, f0b1, f0a2, f0b2, f0a3, f0b3;                                                   // B nq=0: [ks]
+  uint2 f1a0, f1b0, f1a1, f1b1, f1a2, f1b2, f1a3, f1b3;                                                   // B nq=1
+  for (int kt = 0; kt < nk; ++kt) {
+    const int st = kt & 1;
+    const unsigned so = (unsigned)(st * PSTAGE);
+    const unsigned sa0 = a_l0 + so, sa1 = a_l1 + so, sb0 = b_l0 + so, sb1 = b_l1 + so;
+    const bool has_a = kt + 1 < nk, has_b = kt + 2 < nk;
+    unsigned char* const dA = ldsA + (st ^ 1) * PSTAGE;
+    unsigned char* const dB = ldsB + st * PSTAGE;
+    const int ma = mbeg + (kt + 1) * 64, mb = mbeg + (kt + 2) * 64;
+    // ---- phase 1: quadrant (0,0); A0(kt+1)
+    ZS_WP_READ_A(0)
+    ZS_WP_READ_B(f0, sb0)
+    const T* s0 = y_ptr(ma + k0, yc0);
+    const T* s1 = y_ptr(ma + k1, yc1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    ZS_WP_QUAD(c000, c001, f0, has_a, s0, dA, s1, dA + 1024)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 2: quadrant (0,1); A1(kt+1); bias partial sums of this tile
+    ZS_WP_READ_B(f1, sb1)
+    s0 = y_ptr(ma + k0, yc0 + 128);
+    s1 = y_ptr(ma + k1, yc1 + 128);
+    if (do_bias) {
+      u32x4_t v0, v1, v2, v3;
+      const unsigned ba = bias_addr + so;
+      ZS_DSR(v0, ba, 0); ZS_DSR(v1, ba, 2048); ZS_DSR(v2, ba, 4096); ZS_DSR(v3, ba, 6144);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned w[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        bsum[2 * (i & 3)] += __uint_as_float(w[i] << 16);
+        bsum[2 * (i & 3) + 1] += __uint_as_float(w[i] & 0xffff0000u);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    ZS_WP_QUAD(c010, c011, f1, has_a, s0, dA + 16384, s1, dA + 16384 + 1024)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 3: quadrant (1,1); B0(kt+2)
+    ZS_WP_READ_A(8192)
+    bool ok0, ok1;
+    const T* r0 = x_row(mb + k0, ok0);
+    const T* r1 = x_row(mb + k1, ok1);
+    s0 = (ok0 && xc0 < p.x_cols) ? r0 + xc0 : zline;
+    s1 = (ok1 && xc1 < p.x_cols) ? r1 + xc1 : zline;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    ZS_WP_QUAD(c110, c111, f1, has_b, s0, dB, s1, dB + 1024)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 4: quadrant (1,0); B1(kt+2); the counted waits for tile kt+1
+    s0 = (ok0 && xc0 + 128 < p.x_cols) ? r0 + xc0 + 128 : zline;
+    s1 = (ok1 && xc1 + 128 < p.x_cols) ? r1 + xc1 + 128 : zline;
+    if (grp1) {
+      if (has_b) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    ZS_WP_QUAD(c100, c101, f0, has_b, s0, dB + 16384, s1, dB + 16384 + 1024)
+    if (!grp1) {
+      if (has_b) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (!grp1) __builtin_amdgcn_s_barrier();          // pairs with group 1's last barrier
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  if (do_bias) {
+    // red[group][16 row lanes][128 channels] fp32 = 16 KiB; fixed summation order -> deterministic
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(wr * 16 + kr0) * 128 + seg16 * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < 256) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += red[((tid >> 7) * 16 + r) * 128 + (tid & 127)];
+      float* bslab = (float*)p.workspace + (int64_t)gridDim.y * cout_r * p.taps * cin_r + (int64_t)blockIdx.y * cout_r;
+      bslab[co0 + tid] = t;
+    }
+    __syncthreads();
+  }
+  // slab[split][co][tap][ci] (co < cout_r, ci < cin_r: whole tiles), staged through LDS in two 128-ci halves
+  float* slab = (float*)p.workspace + (int64_t)blockIdx.y * cout_r * p.taps * cin_r;
+  float* sC = reinterpret_cast<float*>(smem);
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    if ((wc >> 1) == h) {
+      const int cb = (wc & 1) * 64 + (lane & 31);
+      const int rbase = wr * 128 + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ro = (r & 3) + 8 * (r >> 2);
+        sC[(rbase + ro) * CPITCH + cb] = c000[r];            sC[(rbase + 32 + ro) * CPITCH + cb] = c001[r];
+        sC[(rbase + ro) * CPITCH + cb + 32] = c010[r];       sC[(rbase + 32 + ro) * CPITCH + cb + 32] = c011[r];
+        sC[(rbase + 64 + ro) * CPITCH + cb] = c100[r];       sC[(rbase + 96 + ro) * CPITCH + cb] = c101[r];
+        sC[(rbase + 64 + ro) * CPITCH + cb + 32] = c110[r];  sC[(rbase + 96 + ro) * CPITCH + cb + 32] = c111[r];
+      }
+    }
+    __syncthreads();
+    const int cg = tid & 15, rr0 = tid >> 4;          // 16 groups of 8 ci x 32 co rows per pass
+#pragma unroll 1
+    for (int it = 0; it < 8; ++it) {
+      const int row = rr0 + 32 * it;
+      const float4 x0 = *reinterpret_cast<const float4*>(sC + row * CPITCH + cg * 8);
+      const float4 x1 = *reinterpret_cast<const float4*>(sC + row * CPITCH + cg * 8 + 4);
+      float* d = slab + ((int64_t)(co0 + row) * p.taps + tap) * cin_r + ci0 + h * 128 + cg * 8;
+      *reinterpret_cast<float4*>(d) = x0;
+      *reinterpret_cast<float4*>(d + 4) = x1;
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void wgrad_reduce_kernel(const ZsGemmWgrad p, int splits, int cout_r, int cin_r) {
   const int ci = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y;
@@ -887,26 +1458,62 @@ __global__ void wgrad_reduce_kernel(const ZsGemmWgrad p, int splits, int cout_r,
   }
 }
 
-int pick_splits(const ZsGemmWgrad* p) {
-  if (p->splits > 0) return p->splits;
+int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+int g_wgrad_p8 = -1;
+
+struct WgradPlan { int p8, splits, tile, co_tiles, ci_tiles, cout_r, cin_r, rows_per_split; };
+
+// Split-K plan.  128x128 tiles (fp32, small outputs): ~768 workgroups.  256x256 ping-pong tiles (bf16): one workgroup per
+// CU and round, each split pays a 256-KiB slab write + re-read (~13 K-tile times at 1/256 of HBM), so minimise
+// rounds x (K tiles per split + 13).
+WgradPlan wgrad_plan(const ZsGemmWgrad* p) {
+  WgradPlan w;
+  if (g_wgrad_p8 < 0) g_wgrad_p8 = env_int("ZS_WGRAD_P8", 1);
   const int64_t M = (int64_t)p->B * p->T_out;
-  const int64_t tiles = (int64_t)((p->Cout + 127) / 128) * p->taps * ((p->Cin + 127) / 128);
-  int64_t s = (768 + tiles - 1) / tiles;
-  int64_t maxs = (M + 255) / 256;
-  if (s > maxs) s = maxs;
-  if (s > 64) s = 64;
-  if (s < 1) s = 1;
-  return (int)s;
+  const int64_t t256 = (int64_t)((p->Cout + 255) / 256) * p->taps * ((p->Cin + 255) / 256);
+  // padding waste of 256-wide tiles must stay small, and there must be enough K per workgroup to amortise the slab
+  const double waste = (double)(((p->Cout + 255) / 256) * 256) * (((p->Cin + 255) / 256) * 256) / ((double)p->Cout * p->Cin);
+  w.p8 = g_wgrad_p8 && p->dtype == ZS_BF16 && waste <= 1.35 && M >= 2048 && (g_wgrad_p8 > 1 || t256 * M >= (int64_t)16 * 8192);
+  if (g_wgrad_p8 > 1 && p->dtype == ZS_BF16) w.p8 = 1;                 // forced (tests)
+  w.tile = w.p8 ? 256 : 128;
+  w.co_tiles = (p->Cout + w.tile - 1) / w.tile; w.ci_tiles = (p->Cin + w.tile - 1) / w.tile;
+  w.cout_r = w.co_tiles * w.tile; w.cin_r = w.ci_tiles * w.tile;
+  const int64_t tiles = (int64_t)w.co_tiles * p->taps * w.ci_tiles;
+  if (p->splits > 0) {
+    w.splits = p->splits;
+  } else if (w.p8) {
+    const int64_t kt = (M + 63) / 64;
+    double best = 1e30; int bs = 1;
+    for (int sp = 1; sp <= 64 && (int64_t)sp * 4 <= kt; ++sp) {
+      const double rounds = (double)((tiles * sp + 255) / 256);
+      const double cost = rounds * ((double)((kt + sp - 1) / sp) + 13.0);
+      if (cost < best - 1e-9) { best = cost; bs = sp; }
+    }
+    w.splits = bs;
+  } else {
+    int64_t sp = (768 + tiles - 1) / tiles;
+    int64_t maxs = (M + 255) / 256;
+    if (sp > maxs) sp = maxs;
+    if (sp > 64) sp = 64;
+    if (sp < 1) sp = 1;
+    w.splits = (int)sp;
+  }
+  const int gran = w.p8 ? 64 : WK;
+  int rps = (int)((M + w.splits - 1) / w.splits);
+  w.rows_per_split = ((rps + gran - 1) / gran) * gran;
+  return w;
 }
 
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-int g_use_dma = -1, g_use_ring = -1, g_ring_min_tiles = -1;
+int g_use_dma = -1, g_use_ring = -1, g_ring_min_tiles = -1, g_use_pp = -1, g_use_p8 = -1, g_p8_min_tiles = -1;
 void init_options() {
   if (g_use_dma < 0) g_use_dma = env_int("ZS_GEMM_DMA", 1);
   if (g_use_ring < 0) g_use_ring = env_int("ZS_GEMM_RING", 1);
   if (g_ring_min_tiles < 0) g_ring_min_tiles = env_int("ZS_GEMM_RING_MIN_TILES", 256);
+  if (g_use_pp < 0) g_use_pp = env_int("ZS_GEMM_PP", 1);
+  if (g_use_p8 < 0) g_use_p8 = env_int("ZS_GEMM_P8", 1);
+  if (g_p8_min_tiles < 0) g_p8_min_tiles = env_int("ZS_GEMM_P8_MIN_TILES", 200);
 }
 
 }  // namespace
@@ -945,17 +1552,36 @@ extern "C" int zs_gemm_conv(const ZsGemmConv* p, void* stream) {
   init_options();
   const int use_dma = g_use_dma, use_ring = g_use_ring;
   const int64_t ring_tiles = ((M + RBM - 1) / RBM) * ((p->N + BN - 1) / BN);
-  if (use_dma && use_ring && ring_tiles >= g_ring_min_tiles && ring_tiles < (1ll << 31)) {
+  const int64_t p8_tiles = ((M + PBM - 1) / PBM) * ((p->N + PBN - 1) / PBN);
+  if (use_dma && g_use_p8 && p->n_pad % PBN == 0 && p8_tiles >= g_p8_min_tiles && p8_tiles < (1ll << 31)) {
+    // enough 256x256 tiles for most of the chip: quadrant ping-pong kernel
+    dim3 pgrid((unsigned)p8_tiles, 1, (unsigned)groups);
+    static bool p8_attr = false;
+    if (!p8_attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_p8_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_p8_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+      p8_attr = true;
+    }
+    if (p->dtype == ZS_F32) hipLaunchKernelGGL(gemm_conv_p8_kernel<float>, pgrid, dim3(PNT), P8_LDS, s, *p);
+    else hipLaunchKernelGGL(gemm_conv_p8_kernel<bf16_t>, pgrid, dim3(PNT), P8_LDS, s, *p);
+  } else if (use_dma && use_ring && ring_tiles >= g_ring_min_tiles && ring_tiles < (1ll << 31)) {
     // enough 256x128 tiles to give every CU one workgroup: 3-stage ring kernel
     dim3 rgrid((unsigned)ring_tiles, 1, (unsigned)groups);
     static bool attr_set = false;
     if (!attr_set) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_ring_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_ring_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_ring_kernel<float, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_ring_kernel<bf16_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_ring_kernel<float, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_ring_kernel<bf16_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);
       attr_set = true;
     }
-    if (p->dtype == ZS_F32) hipLaunchKernelGGL(gemm_conv_ring_kernel<float>, rgrid, dim3(RNT), RING_LDS, s, *p);
-    else hipLaunchKernelGGL(gemm_conv_ring_kernel<bf16_t>, rgrid, dim3(RNT), RING_LDS, s, *p);
+    if (g_use_pp) {
+      if (p->dtype == ZS_F32) hipLaunchKernelGGL((gemm_conv_ring_kernel<float, 1>), rgrid, dim3(RNT), RING_LDS, s, *p);
+      else hipLaunchKernelGGL((gemm_conv_ring_kernel<bf16_t, 1>), rgrid, dim3(RNT), RING_LDS, s, *p);
+    } else {
+      if (p->dtype == ZS_F32) hipLaunchKernelGGL((gemm_conv_ring_kernel<float, 0>), rgrid, dim3(RNT), RING_LDS, s, *p);
+      else hipLaunchKernelGGL((gemm_conv_ring_kernel<bf16_t, 0>), rgrid, dim3(RNT), RING_LDS, s, *p);
+    }
   } else if (use_dma) {
     const size_t lds = (4 * DTILE > EPI_LDS_BYTES) ? 4 * DTILE : EPI_LDS_BYTES;
     if (p->dtype == ZS_F32) hipLaunchKernelGGL(gemm_conv_dma_kernel<float>, grid, dim3(NT), lds, s, *p);
@@ -974,6 +1600,10 @@ extern "C" int zs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "gemm_dma")) slot = &g_use_dma;
   else if (key && !strcmp(key, "gemm_ring")) slot = &g_use_ring;
   else if (key && !strcmp(key, "gemm_ring_min_tiles")) slot = &g_ring_min_tiles;
+  else if (key && !strcmp(key, "gemm_pp")) slot = &g_use_pp;
+  else if (key && !strcmp(key, "gemm_p8")) slot = &g_use_p8;
+  else if (key && !strcmp(key, "gemm_p8_min_tiles")) slot = &g_p8_min_tiles;
+  else if (key && !strcmp(key, "wgrad_p8")) { if (g_wgrad_p8 < 0) g_wgrad_p8 = env_int("ZS_WGRAD_P8", 1); slot = &g_wgrad_p8; }
   if (!slot) { zs_set_error("zs_set_option: unknown key %s", key ? key : "(null)"); return ZS_EINVAL; }
   const int old = *slot;
   *slot = value;
@@ -982,8 +1612,8 @@ extern "C" int zs_set_option(const char* key, int value) {
 
 extern "C" size_t zs_gemm_wgrad_workspace_bytes(const ZsGemmWgrad* p) {
   if (!p) return 0;
-  const int64_t cout_r = (int64_t)((p->Cout + 127) / 128) * 128, cin_r = (int64_t)((p->Cin + 127) / 128) * 128;
-  return (size_t)pick_splits(p) * (cout_r * p->taps * cin_r + cout_r) * sizeof(float);
+  const WgradPlan w = wgrad_plan(p);
+  return (size_t)w.splits * ((size_t)w.cout_r * p->taps * w.cin_r + w.cout_r) * sizeof(float);
 }
 
 extern "C" int zs_gemm_wgrad(const ZsGemmWgrad* p, void* stream) {
@@ -998,20 +1628,24 @@ extern "C" int zs_gemm_wgrad(const ZsGemmWgrad* p, void* stream) {
              "zs_gemm_wgrad: operands must be 16-byte aligned");
   ZS_REQUIRE(p->y_cols <= p->ldy && p->x_cols <= p->ldx && p->Cout <= p->y_cols && p->Cin <= p->x_cols, "zs_gemm_wgrad: column bounds");
   ZS_REQUIRE(!p->co_split2 || p->Cout % 2 == 0, "zs_gemm_wgrad: SPLIT2 needs even Cout");
-  const int splits = pick_splits(p);
-  const int co_tiles = (p->Cout + 127) / 128, ci_tiles = (p->Cin + 127) / 128;
-  const int cout_r = co_tiles * 128, cin_r = ci_tiles * 128;
+  const WgradPlan w = wgrad_plan(p);
+  const int splits = w.splits, co_tiles = w.co_tiles, ci_tiles = w.ci_tiles, cout_r = w.cout_r, cin_r = w.cin_r;
+  const int rows_per_split = w.rows_per_split;
   const size_t need = (size_t)splits * ((size_t)cout_r * p->taps * cin_r + cout_r) * sizeof(float);
   if (p->workspace_bytes < need) {
     zs_set_error("zs_gemm_wgrad: workspace %zu < %zu bytes", p->workspace_bytes, need);
     return ZS_EWORKSPACE;
   }
-  const int64_t M = (int64_t)p->B * p->T_out;
-  int rows_per_split = (int)((M + splits - 1) / splits);
-  rows_per_split = ((rows_per_split + WK - 1) / WK) * WK;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)(co_tiles * p->taps * ci_tiles), (unsigned)splits, 1);
-  if (p->dtype == ZS_F32) {
+  if (w.p8) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_p8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+      attr = true;
+    }
+    hipLaunchKernelGGL(gemm_wgrad_p8_kernel, grid, dim3(PNT), P8_LDS, s, *p, ci_tiles, rows_per_split, cout_r, cin_r);
+  } else if (p->dtype == ZS_F32) {
     const size_t lds = (4 * WK * WFrag<float>::PITCHW > EPI_LDS_BYTES) ? 4 * WK * WFrag<float>::PITCHW : EPI_LDS_BYTES;
     hipLaunchKernelGGL(gemm_wgrad_kernel<float>, grid, dim3(NT), lds, s, *p, ci_tiles, rows_per_split, cout_r, cin_r);
   } else {
