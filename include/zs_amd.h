@@ -42,6 +42,13 @@ const char* zs_last_error(void);
  *   "gemm_dma" (ZS_GEMM_DMA, 1): LDS-DMA operand staging; 0 = register-staged kernel
  *   "gemm_ring" (ZS_GEMM_RING, 1): allow the 256x128 3-stage-ring kernel
  *   "gemm_ring_min_tiles" (ZS_GEMM_RING_MIN_TILES, 256): use it when the problem has at least that many 256x128 tiles
+ *   "gemm_pp" (ZS_GEMM_PP, 1): ping-pong schedule of the ring kernel (two wave groups one barrier apart)
+ *   "gemm_p8" (ZS_GEMM_P8, 1) / "gemm_p8_min_tiles" (ZS_GEMM_P8_MIN_TILES, 200): 256x256 quadrant ping-pong kernel when the
+ *       packed weight has a multiple of 256 rows and the problem has at least that many 256x256 tiles
+ *   "wgrad_p8" (ZS_WGRAD_P8, 1): 256x256 ping-pong weight-gradient kernel (bf16) where its heuristics accept the shape;
+ *       0 = always the 128x128 kernel, 2 = whenever bf16 (tests)
+ *   "gru_persist" (ZS_GRU_PERSIST, 0): 1 = one persistent launch per GRU forward pass (time loop on the device) when the
+ *       grid fits one workgroup per CU (measured slower than one launch per time step: off by default)
  * Returns the previous value, or ZS_EINVAL for an unknown key. */
 int zs_set_option(const char* key, int value);
 
@@ -127,6 +134,8 @@ typedef struct {
   const int32_t* row_perm;         /* optional: output row n reads parameter row row_perm[n] (overrides co_split2) */
 } ZsPackWeight;
 int zs_pack_weight(const ZsPackWeight* p, void* stream);
+/* the same for n jobs (one dtype) in ceil(n/32) launches: the per-step repack of a whole net after the optimiser step */
+int zs_pack_weight_batch(const ZsPackWeight* jobs, int32_t n, void* stream);
 
 /* zs_cast_rows: dst[r][col_off + c] = f(src[r][c]) for c < cols, zeros for cols <= c < fill_cols.
  * f = identity or leaky_relu (model/model.py:446).  src fp32 or T (src_f32), dst T or fp32. */

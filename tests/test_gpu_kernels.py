@@ -331,10 +331,21 @@ def test_mbv_bit_exact_and_grad(zs):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('shape', [(3, 5, 24, 16), (2, 16, 32, 32), (70, 6, 64, 64), (5, 9, 40, 96)])
-def test_gru(zs, dtype, shape):
-    """Bidirectional GRU forward + BPTT + all parameter gradients vs. the oracle GRU under autograd."""
+@pytest.mark.parametrize('persist', [1, 0])
+@pytest.mark.parametrize('shape', [(3, 5, 24, 16), (2, 16, 32, 32), (70, 6, 64, 64), (5, 9, 40, 96), (40, 12, 48, 128), (33, 7, 32, 256),
+                                   (64, 10, 64, 512)])
+def test_gru(zs, dtype, shape, persist):
+    """Bidirectional GRU forward + BPTT + all parameter gradients vs. the oracle GRU under autograd; with the persistent
+    time-loop kernels (where H and the grid size allow them) and with one launch per step."""
     L, layers = zs
+    old_persist = L.set_option('gru_persist', persist)
+    try:
+        _gru_case(L, layers, dtype, shape)
+    finally:
+        L.set_option('gru_persist', old_persist)
+
+
+def _gru_case(L, layers, dtype, shape):
     import zs_oracle as O
     B, T, Cin, H = shape
     g = torch.Generator().manual_seed(2)

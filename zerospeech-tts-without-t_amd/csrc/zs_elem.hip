@@ -1,5 +1,7 @@
 // zs_elem.hip -- HBM-bound elementwise / reduction kernels of the autoencoder path: weight packing,
 // casts, speaker-embedding adds and gradient scatter, the MBV discretiser, L1 loss, grad-norm, Adam, CE.
+#include <string.h>
+
 #include "zs_common.h"
 
 namespace {
@@ -11,9 +13,9 @@ template <typename T> __device__ __forceinline__ void stT(void* p, int64_t i, fl
 
 // ---- pack_weight ---------------------------------------------------------------------------------
 template <typename T>
-__global__ void pack_weight_kernel(const ZsPackWeight p) {
+__device__ __forceinline__ void pack_weight_body(const ZsPackWeight& p, int64_t first, int64_t step) {
   const int64_t total = (int64_t)p.n_rows * p.n_cols;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = first; i < total; i += step) {
     const int row = (int)(i / p.n_cols);
     const int k = (int)(i - (int64_t)row * p.n_cols);
     const int tap = k / p.inner_pad, inner = k - tap * p.inner_pad;
@@ -27,6 +29,21 @@ __global__ void pack_weight_kernel(const ZsPackWeight p) {
     }
     stT<T>(p.dst, (int64_t)(row + p.row_offset) * p.ldw + p.col_offset + k, v);
   }
+}
+
+template <typename T>
+__global__ void pack_weight_kernel(const ZsPackWeight p) {
+  pack_weight_body<T>(p, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+}
+
+// up to PACK_BATCH jobs per launch (the per-step repack of a net is ~40 small jobs: one launch instead of 40)
+constexpr int PACK_BATCH = 32;
+struct PackBatch { ZsPackWeight job[PACK_BATCH]; };
+
+template <typename T>
+__global__ void pack_weight_batch_kernel(const PackBatch b) {
+  const ZsPackWeight& p = b.job[blockIdx.y];
+  pack_weight_body<T>(p, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
 
 // ---- cast_rows -------------------------------------------------------------------------------------
@@ -261,7 +278,7 @@ inline unsigned nblocks(int64_t total, int cap = 2048) {
     else hipLaunchKernelGGL(KERNEL<bf16_t>, grid, block, 0, (hipStream_t)(stream), __VA_ARGS__);          \
   } while (0)
 
-extern "C" int zs_pack_weight(const ZsPackWeight* p, void* stream) {
+static int pack_check(const ZsPackWeight* p) {
   ZS_REQUIRE(p && p->W && p->dst, "zs_pack_weight: null operand");
   ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_pack_weight: bad dtype");
   ZS_REQUIRE(p->Cout > 0 && p->Cin > 0 && p->taps > 0 && p->inner_pad > 0 && p->n_rows > 0 && p->n_cols > 0 &&
@@ -269,8 +286,38 @@ extern "C" int zs_pack_weight(const ZsPackWeight* p, void* stream) {
              "zs_pack_weight: sizes (ldw %lld n_cols %d taps %d inner_pad %d)", (long long)p->ldw, p->n_cols, p->taps, p->inner_pad);
   ZS_REQUIRE((p->transpose ? p->Cout : p->Cin) <= p->inner_pad, "zs_pack_weight: inner_pad too small");
   ZS_REQUIRE(!p->co_split2 || p->Cout % 2 == 0, "zs_pack_weight: SPLIT2 needs even Cout");
+  return ZS_OK;
+}
+
+extern "C" int zs_pack_weight(const ZsPackWeight* p, void* stream) {
+  int rc = pack_check(p);
+  if (rc) return rc;
   ZS_DISPATCH(p->dtype, pack_weight_kernel, dim3(nblocks((int64_t)p->n_rows * p->n_cols, 4096)), dim3(NTE), stream, *p);
   return zs_check_launch("zs_pack_weight");
+}
+
+extern "C" int zs_pack_weight_batch(const ZsPackWeight* jobs, int32_t n, void* stream) {
+  ZS_REQUIRE(jobs && n > 0, "zs_pack_weight_batch: no jobs");
+  for (int i = 0; i < n; ++i) {
+    int rc = pack_check(jobs + i);
+    if (rc) return rc;
+    ZS_REQUIRE(jobs[i].dtype == jobs[0].dtype, "zs_pack_weight_batch: mixed dtypes");
+  }
+  for (int i0 = 0; i0 < n; i0 += PACK_BATCH) {
+    const int m = n - i0 < PACK_BATCH ? n - i0 : PACK_BATCH;
+    PackBatch b;
+    memset(&b, 0, sizeof(b));
+    unsigned gx = 1;
+    for (int i = 0; i < m; ++i) {
+      b.job[i] = jobs[i0 + i];
+      const unsigned nb = nblocks((int64_t)jobs[i0 + i].n_rows * jobs[i0 + i].n_cols, 4096);
+      if (nb > gx) gx = nb;
+    }
+    ZS_DISPATCH(jobs[0].dtype, pack_weight_batch_kernel, dim3(gx, (unsigned)m), dim3(NTE), stream, b);
+    int rc = zs_check_launch("zs_pack_weight_batch");
+    if (rc) return rc;
+  }
+  return ZS_OK;
 }
 
 extern "C" int zs_cast_rows(const ZsCastRows* p, void* stream) {

@@ -1437,23 +1437,48 @@ __global__ __launch_bounds__(PNT, 2) void gemm_wgrad_p8_kernel(const ZsGemmWgrad
   }
 }
 
-__global__ void wgrad_reduce_kernel(const ZsGemmWgrad p, int splits, int cout_r, int cin_r) {
-  const int ci = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y;
-  const int co = blockIdx.z;
-  if (ci >= p.Cin) return;
+// Fixed-order sum of the split-K slabs (deterministic): one thread per 4 consecutive ci of a (co, tap) row, eight slab
+// loads in flight per thread (the slab pitch cin_r is a multiple of 128, so the float4 loads are aligned and in bounds).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ZsGemmWgrad p, int splits, int cout_r, int cin_r) {
+  const int cin4 = (p.Cin + 3) >> 2;
+  const int64_t total = (int64_t)p.Cout * p.taps * cin4;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c4 = (int)(idx % cin4);
+  const int64_t rowi = idx / cin4;
+  const int j = (int)(rowi % p.taps);
+  const int co = (int)(rowi / p.taps);
   const int half = p.Cout >> 1;
   const int cop = p.co_split2 ? ((co & 1) * half + (co >> 1)) : co;
-  const float* ws = (const float*)p.workspace + ((int64_t)cop * p.taps + j) * cin_r + ci;
   const int64_t sstride = (int64_t)cout_r * p.taps * cin_r;
-  float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += ws[k * sstride];
-  float* d = p.dW + (int64_t)co * p.so + (int64_t)ci * p.si + (int64_t)j * p.sj;
-  *d = p.accumulate ? (*d + s) : s;
-  if (p.db != nullptr && ci == 0 && j == 0) {
+  const float* ws = (const float*)p.workspace + ((int64_t)cop * p.taps + j) * cin_r + c4 * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int k = 0;
+  for (; k + 8 <= splits; k += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(ws + (int64_t)(k + u) * sstride);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+  }
+  for (; k < splits; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(ws + (int64_t)k * sstride);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  const float r[4] = {acc.x, acc.y, acc.z, acc.w};
+  float* d = p.dW + (int64_t)co * p.so + (int64_t)j * p.sj;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int ci = c4 * 4 + e;
+    if (ci < p.Cin) {
+      float* q = d + (int64_t)ci * p.si;
+      *q = p.accumulate ? (*q + r[e]) : r[e];
+    }
+  }
+  if (p.db != nullptr && c4 == 0 && j == 0) {
     const float* bs = (const float*)p.workspace + (int64_t)splits * sstride + cop;
     float t = 0.f;
-    for (int k = 0; k < splits; ++k) t += bs[(int64_t)k * cout_r];
+    for (int q2 = 0; q2 < splits; ++q2) t += bs[(int64_t)q2 * cout_r];
     p.db[co] = p.accumulate ? (p.db[co] + t) : t;
   }
 }
@@ -1604,6 +1629,7 @@ extern "C" int zs_set_option(const char* key, int value) {
   else if (key && !strcmp(key, "gemm_p8")) slot = &g_use_p8;
   else if (key && !strcmp(key, "gemm_p8_min_tiles")) slot = &g_p8_min_tiles;
   else if (key && !strcmp(key, "wgrad_p8")) { if (g_wgrad_p8 < 0) g_wgrad_p8 = env_int("ZS_WGRAD_P8", 1); slot = &g_wgrad_p8; }
+  if (key && !strcmp(key, "gru_persist")) return zs_gru_persist_option(value);
   if (!slot) { zs_set_error("zs_set_option: unknown key %s", key ? key : "(null)"); return ZS_EINVAL; }
   const int old = *slot;
   *slot = value;
@@ -1654,7 +1680,7 @@ extern "C" int zs_gemm_wgrad(const ZsGemmWgrad* p, void* stream) {
   }
   int rc = zs_check_launch("zs_gemm_wgrad");
   if (rc) return rc;
-  dim3 rgrid((unsigned)((p->Cin + 127) / 128), (unsigned)p->taps, (unsigned)p->Cout);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(128), 0, s, *p, splits, cout_r, cin_r);
+  const int64_t relems = (int64_t)p->Cout * p->taps * ((p->Cin + 3) / 4);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((relems + 255) / 256)), dim3(256), 0, s, *p, splits, cout_r, cin_r);
   return zs_check_launch("zs_gemm_wgrad.reduce");
 }

@@ -6,6 +6,9 @@
 //   forward :  r = s(gi_r + gh_r + b_hr)  z = s(gi_z + gh_z + b_hz)  n = tanh(gi_n + r*(gh_n + b_hn))
 //              h = (1-z)*n + z*h_prev
 //   backward:  BPTT with dh carried as (direct part dh*z) + (dgh W_hh) computed by the same product kernel.
+#include <stdlib.h>
+#include <string.h>
+
 #include "zs_common.h"
 
 namespace {
@@ -323,13 +326,240 @@ __global__ __launch_bounds__(256) void rowblock_gemm_kernel(const RowGemmArgs a)
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent recurrence: ONE launch per layer and direction pair; the loop over time runs inside the kernel.
+// Workgroup (hc, rb, dir) owns 32 hidden units x 32 batch rows for all T steps.  Its slice of W_hh (96 rows x H,
+// 96 KiB in bf16 at H = 512) is loaded into registers once (each of the 4 waves keeps its quarter of K); per step it
+// only reads h_{t-1} of its 32 rows (written one step earlier by the H/32 workgroups of the same (rb, dir) group), runs
+// the MFMAs, reduces over the 4 waves through LDS, does the gate math for its (row, unit) elements (h_prev stays in a
+// register) and publishes its 32x32 slice of h_t.
+// Hand-off between the workgroups of a group (cdna guide, inter-workgroup communication):
+//   producer: h_t stored write-through (relaxed agent-scope atomic stores = sc1) -> every wave s_waitcnt vmcnt(0) ->
+//             __syncthreads -> one lane adds 1 to the group's arrival counter (agent-scope atomic)
+//   consumer: one lane polls the counter (relaxed agent-scope loads, s_sleep) until it reaches (H/32)*s -> barrier ->
+//             h_{t-1} fragments are read with agent-scope (sc1) loads, which bypass this CU's L1: no acquire fence.
+// Spins are bounded: on timeout the error word is set and the workgroup stops waiting (results are then wrong, never a
+// hang).  The whole grid (<= one workgroup per CU) must be able to be resident: checked on the host.
+// MEASURED (MI355X, B=256 T=128 H=512 bf16): 13.7 us per step against 11.1 us for one launch per step -- the
+// store-drain -> counter -> poll -> write-through re-read chain costs more than a kernel boundary (1.5-1.9 us) plus an
+// L2-resident re-read of W_hh -- so the option "gru_persist" is OFF by default and the kernel is kept as the tested
+// starting point for a data-tagged (flag-less) hand-off.
+// ------------------------------------------------------------------------------------------------
+struct GruPersistArgs {
+  const void* gi; int64_t ldgi;
+  const void* whh; int64_t ldw; int64_t w_gstride;
+  const float* bhh; int64_t bhh_gstride;
+  void* out; int64_t ldo; int out_col;
+  void* gates;
+  unsigned* cnt;                 // [2][nrb] arrival counters + error word at [2*nrb]; zeroed before the launch
+  int B, T, H, nrb;
+  // backward only
+  const void* dout; int64_t ldd; int dout_col;
+  void* dgi; int64_t ldgi_b;
+  void* dgh; int64_t ldgh;
+};
+
+typedef __attribute__((address_space(1))) unsigned long long gu64_t;
+typedef __attribute__((address_space(1))) unsigned gu32_t;
+
+// 16-byte agent-scope (sc1: bypasses this CU's L1) load.  Inline asm so that all fragment loads of a step are in flight
+// together (hipcc issues relaxed atomic loads one at a time, each behind a wait); the caller waits with s_waitcnt vmcnt(0).
+typedef __attribute__((ext_vector_type(4))) unsigned gu32x4_t;
+__device__ __forceinline__ void load16_sc1_issue(gu32x4_t& dst, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory");
+}
+template <typename T> struct Pair;
+template <> struct Pair<bf16_t> {
+  static __device__ __forceinline__ void ld(const bf16_t* p, float& a, float& b) {
+    const unsigned w = *reinterpret_cast<const unsigned*>(p);
+    a = __uint_as_float(w << 16); b = __uint_as_float(w & 0xffff0000u);
+  }
+  static __device__ __forceinline__ unsigned pack(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+  static __device__ __forceinline__ void st(bf16_t* p, float a, float b) { *reinterpret_cast<unsigned*>(p) = pack(a, b); }
+  static __device__ __forceinline__ void st_sc1(bf16_t* p, float a, float b) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), pack(a, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // what the consumer will read back (rounded to T)
+  static __device__ __forceinline__ float rnd(float a) { return bf2f(f2bf(a)); }
+};
+template <> struct Pair<float> {
+  static __device__ __forceinline__ void ld(const float* p, float& a, float& b) { const float2 v = *reinterpret_cast<const float2*>(p); a = v.x; b = v.y; }
+  static __device__ __forceinline__ void st(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
+  static __device__ __forceinline__ void st_sc1(float* p, float a, float b) {
+    const unsigned long long w = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  static __device__ __forceinline__ float rnd(float a) { return a; }
+};
+
+constexpr unsigned GRU_SPIN_LIMIT = 1u << 22;
+
+// wait until the group's counter reaches `want` (one lane polls; everyone leaves through the barrier)
+__device__ __forceinline__ void gru_group_wait(unsigned* cnt, unsigned* err, unsigned want, int tid) {
+  if (tid == 0) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > GRU_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // compiler: keep the h loads below the poll
+}
+__device__ __forceinline__ void gru_group_arrive(unsigned* cnt, int tid) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every storing wave drains its write-through stores
+  __syncthreads();
+  if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename T, int PER>     // PER = k-steps (of Frag16<T>::KSTEP) per wave: H = 4 * PER * KSTEP
+__global__ __launch_bounds__(256) void gru_persist_fwd_kernel(const GruPersistArgs a) {
+  constexpr int KSTEP = Frag16<T>::KSTEP;
+  constexpr int EPL = 16 / (int)sizeof(T);
+  __shared__ float part[4][RB][6][4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, r = lane & 15;
+  const int d = blockIdx.z, H = a.H, T_ = a.T;
+  const int m0 = blockIdx.y * 16 * RB;
+  unsigned* cnt = a.cnt + d * a.nrb + blockIdx.y;
+  unsigned* err = a.cnt + 2 * a.nrb;
+  const unsigned group = (unsigned)(H / 32);
+
+  // W_hh slice of this workgroup, this wave's K quarter: registers for the whole sequence
+  uint4 fb[PER][6];
+  {
+    const T* Wrow = (const T*)a.whh + (int64_t)d * a.w_gstride + (int64_t)(blockIdx.x * 96 + r) * a.ldw + q * EPL;
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) fb[u][c] = *reinterpret_cast<const uint4*>(Wrow + (int64_t)(16 * c) * a.ldw + (wave * PER + u) * KSTEP);
+  }
+  // A rows of the fragments
+  const T* Abase[RB];
+  bool rvalid[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int row = m0 + 16 * rb + r;
+    rvalid[rb] = row < a.B;
+    Abase[rb] = (const T*)a.out + (int64_t)(rvalid[rb] ? row : 0) * T_ * a.ldo + a.out_col + d * H + q * EPL + wave * PER * KSTEP;
+  }
+  // epilogue ownership: unit pair (2*eu2, 2*eu2+1) of the 32 units, rows e_row + 16*pz
+  const int eu2 = tid & 15, e_row = tid >> 4;
+  const int j = blockIdx.x * 32 + 2 * eu2;
+  const int hh = (2 * eu2) >> 4, cc = (2 * eu2) & 15;
+  const float* bh = a.bhh + (int64_t)d * a.bhh_gstride;
+  const float b_r0 = bh[j], b_r1 = bh[j + 1], b_z0 = bh[H + j], b_z1 = bh[H + j + 1], b_n0 = bh[2 * H + j], b_n1 = bh[2 * H + j + 1];
+  float hp[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+
+  for (int s = 0; s < T_; ++s) {
+    const int t = d == 0 ? s : T_ - 1 - s;
+    // gate inputs of this step do not depend on other workgroups: issue them before the wait
+    float gi_r[2][2], gi_z[2][2], gi_n[2][2];
+#pragma unroll
+    for (int pz = 0; pz < 2; ++pz) {
+      const int b = m0 + e_row + 16 * pz;
+      gi_r[pz][0] = gi_r[pz][1] = gi_z[pz][0] = gi_z[pz][1] = gi_n[pz][0] = gi_n[pz][1] = 0.f;
+      if (b < a.B) {
+        const T* gi = (const T*)a.gi + ((int64_t)b * T_ + t) * a.ldgi + (int64_t)d * 3 * H + j;
+        Pair<T>::ld(gi, gi_r[pz][0], gi_r[pz][1]); Pair<T>::ld(gi + H, gi_z[pz][0], gi_z[pz][1]); Pair<T>::ld(gi + 2 * H, gi_n[pz][0], gi_n[pz][1]);
+      }
+    }
+    f32x4_t acc[RB][6];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc[rb][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
+      gru_group_wait(cnt, err, group * (unsigned)s, tid);
+      const int tp = d == 0 ? t - 1 : t + 1;
+      gu32x4_t fr[PER][RB];
+#pragma unroll
+      for (int u = 0; u < PER; ++u)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) load16_sc1_issue(fr[u][rb], Abase[rb] + (int64_t)tp * a.ldo + u * KSTEP);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);             // nothing that reads fr[][] may be scheduled above the wait
+#pragma unroll
+      for (int u = 0; u < PER; ++u)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) asm volatile("" : "+v"(fr[u][rb]));    // ... and the values are defined only from here on
+#pragma unroll
+      for (int u = 0; u < PER; ++u)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          uint4 fa = make_uint4(fr[u][rb].x, fr[u][rb].y, fr[u][rb].z, fr[u][rb].w);
+          if (!rvalid[rb]) fa = make_uint4(0, 0, 0, 0);
+#pragma unroll
+          for (int c = 0; c < 6; ++c) Frag16<T>::mma(fa, fb[u][c], acc[rb][c]);
+        }
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[wave][rb][c][i][lane] = acc[rb][c][i];
+    __syncthreads();
+    auto total = [&](int c, int rr, int col) -> float {
+      const int rb = rr >> 4, l = ((rr & 15) >> 2) * 16 + col, i = rr & 3;
+      return (part[0][rb][c][i][l] + part[1][rb][c][i][l]) + (part[2][rb][c][i][l] + part[3][rb][c][i][l]);
+    };
+#pragma unroll
+    for (int pz = 0; pz < 2; ++pz) {
+      const int rr = e_row + 16 * pz;
+      const int b = m0 + rr;
+      if (b < a.B) {
+        float hv[2], rg[2], zg[2], ng[2], hn[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float ghr = total(hh, rr, cc + e), ghz = total(2 + hh, rr, cc + e), ghn = total(4 + hh, rr, cc + e);
+          rg[e] = 1.f / (1.f + expf(-(gi_r[pz][e] + (ghr + (e ? b_r1 : b_r0)))));
+          zg[e] = 1.f / (1.f + expf(-(gi_z[pz][e] + (ghz + (e ? b_z1 : b_z0)))));
+          hn[e] = ghn + (e ? b_n1 : b_n0);
+          ng[e] = tanhf(gi_n[pz][e] + rg[e] * hn[e]);
+          hv[e] = (1.f - zg[e]) * ng[e] + zg[e] * hp[pz][e];
+          hp[pz][e] = hv[e];
+        }
+        Pair<T>::st_sc1((T*)a.out + ((int64_t)b * T_ + t) * a.ldo + a.out_col + d * H + j, hv[0], hv[1]);
+        if (a.gates) {
+          T* gs = (T*)a.gates + (((int64_t)b * T_ + t) * 2 + d) * 4 * H + j;
+          Pair<T>::st(gs, rg[0], rg[1]); Pair<T>::st(gs + H, zg[0], zg[1]); Pair<T>::st(gs + 2 * H, ng[0], ng[1]); Pair<T>::st(gs + 3 * H, hn[0], hn[1]);
+        }
+      }
+    }
+    if (s + 1 < T_) gru_group_arrive(cnt, tid);      // also the barrier that frees `part` for the next step
+  }
+}
+
 inline unsigned gate_blocks(int64_t total) {
   int64_t b = (total + NTG - 1) / NTG;
   if (b > 2048) b = 2048;
   return (unsigned)(b < 1 ? 1 : b);
 }
 
+int g_gru_persist = -1;
+bool gru_persist_enabled() {
+  if (g_gru_persist < 0) { const char* e = getenv("ZS_GRU_PERSIST"); g_gru_persist = e ? atoi(e) : 0; }
+  return g_gru_persist != 0;
+}
+// workgroups that are certainly co-resident: one per CU
+int64_t gru_resident_limit() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
 }  // namespace
+
+// "gru_persist" knob of zs_set_option
+int zs_gru_persist_option(int value) { const int old = gru_persist_enabled() ? 1 : 0; g_gru_persist = value ? 1 : 0; return old; }
 
 extern "C" size_t zs_gru_work_bytes(int32_t B, int32_t H) {
   // gh [2][B][3H] + hstate/dhd [2][B][H] + dhg [2][B][H], fp32
@@ -349,6 +579,26 @@ extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
   float* hstate = p->work + (size_t)2 * B * 3 * H;
   const char* outb = (const char*)p->out;
   if (p->whh_interleaved && H % 32 == 0) {
+    // persistent kernel: the time loop runs on the device (see gru_persist_fwd_kernel)
+    const int nrb = (B + 16 * RB - 1) / (16 * RB);
+    const int kstep = p->dtype == ZS_F32 ? 16 : 32;
+    const int per = (H % (4 * kstep) == 0) ? H / (4 * kstep) : 0;
+    const int64_t nwg = (int64_t)(H / 32) * nrb * 2;
+    if (gru_persist_enabled() && (per == 1 || per == 2 || per == 4) && nwg <= gru_resident_limit() && 2 * nrb + 1 <= 64 && T > 1) {
+      GruPersistArgs a;
+      memset(&a, 0, sizeof(a));
+      a.gi = p->gi; a.ldgi = p->ldgi; a.whh = p->whh; a.ldw = p->ldw; a.w_gstride = p->w_gstride;
+      a.bhh = p->bhh; a.bhh_gstride = p->bhh_gstride; a.out = p->out; a.ldo = p->ldo; a.out_col = p->out_col; a.gates = p->gates;
+      a.cnt = reinterpret_cast<unsigned*>(p->work + (size_t)2 * B * 5 * H);     // the 256-byte tail of the work buffer
+      a.B = B; a.T = T; a.H = H; a.nrb = nrb;
+      if (hipMemsetAsync(a.cnt, 0, 256, (hipStream_t)stream) != hipSuccess) { zs_set_error("zs_gru_fwd: memset failed"); return ZS_ELAUNCH; }
+      dim3 grid(H / 32, nrb, 2);
+#define ZS_GRU_PF(TT, PP) hipLaunchKernelGGL((gru_persist_fwd_kernel<TT, PP>), grid, dim3(256), 0, (hipStream_t)stream, a)
+      if (p->dtype == ZS_F32) { if (per == 1) ZS_GRU_PF(float, 1); else if (per == 2) ZS_GRU_PF(float, 2); else ZS_GRU_PF(float, 4); }
+      else { if (per == 1) ZS_GRU_PF(bf16_t, 1); else if (per == 2) ZS_GRU_PF(bf16_t, 2); else ZS_GRU_PF(bf16_t, 4); }
+#undef ZS_GRU_PF
+      return zs_check_launch("zs_gru_fwd.persist");
+    }
     // one fused launch per step: recurrent product + gates (see rowblock_gemm_kernel)
     for (int s = 0; s < T; ++s) {
       RowGemmArgs a;

@@ -47,9 +47,10 @@ class EncoderEngine(object):
         self.tape = None
 
     def pack(self):
-        for l in self.layers:
-            l.pack()
-        self.gru.pack()
+        with L.pack_batch(self.ctx.stream):
+            for l in self.layers:
+                l.pack()
+            self.gru.pack()
 
     # ------------------------------------------------------------------------------------------
     def forward(self, x, training, noise=None, noise_kind=2, seed=0, drop_masks=None, seed_ptr=None):
@@ -234,9 +235,10 @@ class DecoderEngine(object):
         self.tape = None
 
     def pack(self):
-        for l in self.layers:
-            l.pack()
-        self.gru.pack()
+        with L.pack_batch(self.ctx.stream):
+            for l in self.layers:
+                l.pack()
+            self.gru.pack()
 
     def forward(self, bits, cidx, training):
         """bits: Act [B,T',E] (T dtype, zero padded); cidx int64 [B].  Returns x_dec Act fp32 [B, 8T', F]."""
@@ -406,8 +408,9 @@ class ClassifierEngine(object):
         self.tape = None
 
     def pack(self):
-        for l in self.layers:
-            l.pack()
+        with L.pack_batch(self.ctx.stream):
+            for l in self.layers:
+                l.pack()
 
     def forward(self, x, training, seed=0, drop_masks=None):
         """x: Act [B, T', c_in] in the compute dtype.  Returns logits Act fp32 [B, 1, n_class]."""
