@@ -1052,13 +1052,19 @@ __global__ __launch_bounds__(NT, 2) void gemm_wgrad_kernel(const ZsGemmWgrad p, 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+  // 1-D grid, XCD-aware: the workgroups of one K split (same rows of dY and X, different tiles) get consecutive virtual
+  // ids, i.e. the same XCD, so the operand rows are fetched into one L2 instead of all eight
   const int per_co = p.taps * ci_tiles;
-  const int cot = blockIdx.x / per_co;
-  const int rem = blockIdx.x - cot * per_co;
+  const int tiles = ((cout_r / 128) * per_co);
+  const int vid = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = vid / tiles, tile = vid - split * tiles;
+  const int cot = tile / per_co;
+  const int rem = tile - cot * per_co;
   const int tap = rem / ci_tiles, cit = rem - tap * ci_tiles;
   const int co0 = cot * 128, ci0 = cit * 128;
   const int M = p.B * p.T_out;
-  const int mbeg = blockIdx.y * rows_per_split;
+  const int nsplit = gridDim.x / tiles;
+  const int mbeg = split * rows_per_split;
   const int mend = min(M, mbeg + rows_per_split);
   const T* __restrict__ dY = (const T*)p.dY;
   const T* __restrict__ X = (const T*)p.X;
@@ -1150,13 +1156,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_wgrad_kernel(const ZsGemmWgrad p, 
       float t = 0.f;
 #pragma unroll 8
       for (int r = 0; r < WK; ++r) t += red[r * 128 + tid];
-      float* bslab = (float*)p.workspace + (int64_t)gridDim.y * cout_r * p.taps * cin_r + (int64_t)blockIdx.y * cout_r;
+      float* bslab = (float*)p.workspace + (int64_t)nsplit * cout_r * p.taps * cin_r + (int64_t)split * cout_r;
       bslab[co0 + tid] = t;
     }
   }
   // slab[split][co][tap][ci], co < cout_r, ci < cin_r (full tiles: no guards needed).  Accumulators are restaged
   // through LDS so that each thread stores 8 consecutive ci (two 16-byte stores) of a co row.
-  float* slab = (float*)p.workspace + (int64_t)blockIdx.y * cout_r * p.taps * cin_r;
+  float* slab = (float*)p.workspace + (int64_t)split * cout_r * p.taps * cin_r;
   float* sC = reinterpret_cast<float*>(smem);
   __syncthreads();                                  // bias reduction above (if any) is done with LDS
 #pragma unroll
@@ -1228,13 +1234,18 @@ __global__ __launch_bounds__(PNT, 2) void gemm_wgrad_p8_kernel(const ZsGemmWgrad
   typedef __attribute__((address_space(3))) void* lptr_t;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
+  // 1-D grid, XCD-aware: all tiles of one K split (same rows of dY and X) land on one XCD (see gemm_wgrad_kernel)
   const int per_co = p.taps * ci_tiles;
-  const int cot = blockIdx.x / per_co;
-  const int rem = blockIdx.x - cot * per_co;
+  const int tiles = (cout_r / 256) * per_co;
+  const int vid = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = vid / tiles, tile = vid - split * tiles;
+  const int cot = tile / per_co;
+  const int rem = tile - cot * per_co;
   const int tap = rem / ci_tiles, cit = rem - tap * ci_tiles;
   const int co0 = cot * 256, ci0 = cit * 256;
   const int M = p.B * p.T_out;
-  const int mbeg = blockIdx.y * rows_per_split;
+  const int nsplit = gridDim.x / tiles;
+  const int mbeg = split * rows_per_split;
   const int mend = min(M, mbeg + rows_per_split);
   const int nk = (mend - mbeg + 63) / 64;
   const T* __restrict__ dY = (const T*)p.dY;
@@ -1400,13 +1411,13 @@ __global__ __launch_bounds__(PNT, 2) void gemm_wgrad_p8_kernel(const ZsGemmWgrad
       float t = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) t += red[((tid >> 7) * 16 + r) * 128 + (tid & 127)];
-      float* bslab = (float*)p.workspace + (int64_t)gridDim.y * cout_r * p.taps * cin_r + (int64_t)blockIdx.y * cout_r;
+      float* bslab = (float*)p.workspace + (int64_t)nsplit * cout_r * p.taps * cin_r + (int64_t)split * cout_r;
       bslab[co0 + tid] = t;
     }
     __syncthreads();
   }
   // slab[split][co][tap][ci] (co < cout_r, ci < cin_r: whole tiles), staged through LDS in two 128-ci halves
-  float* slab = (float*)p.workspace + (int64_t)blockIdx.y * cout_r * p.taps * cin_r;
+  float* slab = (float*)p.workspace + (int64_t)split * cout_r * p.taps * cin_r;
   float* sC = reinterpret_cast<float*>(smem);
 #pragma unroll 1
   for (int h = 0; h < 2; ++h) {
@@ -1663,7 +1674,8 @@ extern "C" int zs_gemm_wgrad(const ZsGemmWgrad* p, void* stream) {
     return ZS_EWORKSPACE;
   }
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((unsigned)(co_tiles * p->taps * ci_tiles), (unsigned)splits, 1);
+  ZS_REQUIRE((int64_t)co_tiles * p->taps * ci_tiles * splits < (1ll << 31), "zs_gemm_wgrad: grid too large");
+  dim3 grid((unsigned)(co_tiles * p->taps * ci_tiles * splits), 1, 1);
   if (w.p8) {
     static bool attr = false;
     if (!attr) {

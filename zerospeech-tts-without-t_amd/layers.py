@@ -66,6 +66,17 @@ def join_side(device):
         sd['used'] = False
 
 
+_OPT = {}
+
+
+def opt_stream(device):
+    """A third stream: the decoder's clip + Adam + re-pack run here while the encoder's backward is still on the main one."""
+    key = (device.type, device.index)
+    if key not in _OPT:
+        _OPT[key] = torch.cuda.Stream(device)
+    return _OPT[key]
+
+
 class Ctx(object):
     """Per-model execution context: device, compute dtype, cached buffers, split-K workspace."""
 

@@ -17,6 +17,7 @@ import torch
 
 from . import _lib as L
 from . import parallel
+from . import layers
 from .layers import Act, join_side
 from .model import Decoder, Encoder, SpeakerClassifier
 from .utils import Logger
@@ -52,6 +53,8 @@ class AEStep(object):
         self.reducer = parallel.GradReducer()
         self.xdec = None
         self.use_graph = (os.environ.get('ZS_GRAPH', '1') == '1') if use_graph is None else bool(use_graph)
+        self.early_dec_update = os.environ.get('ZS_EARLY_DEC_UPDATE', '1') == '1'
+        self._dec_updated = False
         self._graphs = {}            # (B, T, F) -> dict(graphs=[...], x=static x, c=static c)
         self._eager_calls = 0
         self.graph_warmup = 2        # eager steps (same launches) before the capture
@@ -109,24 +112,51 @@ class AEStep(object):
         if multi:
             join_side(self.device)
             self.reducer.start(dec.flat_params()[1])
+        elif self.early_dec_update:
+            self._early_decoder_update()
         self._seg_encbwd()
         if multi:
             self.reducer.start(enc.flat_params()[1])
             self.reducer.finish()
         self._optimizer_device_step()
 
+    def _net_device_update(self, name, net):
+        """Per-net clip (utils.py:53-55) + Adam with the step count read from device memory + re-pack, on the current stream."""
+        o = self._opt[name]
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        flat, gflat = net.flat_params()
+        L.check(L.lib().zs_sqnorm(L.ptr(gflat), gflat.numel(), L.ptr(o['part']), L.ptr(o['sq']), st), 'zs_sqnorm')
+        b1, b2 = self.betas
+        L.call('zs_adam_clip', 'ZsAdam', st, p=L.ptr(flat), g=L.ptr(gflat), m=L.ptr(o['m']), v=L.ptr(o['v']),
+               n=flat.numel(), lr=self.lr, beta1=b1, beta2=b2, eps=1e-8, bc1=1.0, bc2=1.0, sumsq=L.ptr(o['sq']),
+               max_norm=self.max_grad_norm, write_clipped_grad=0, step_ptr=L.ptr(self._step_dev))
+        net.repack()
+
+    def _early_decoder_update(self):
+        """Single rank: the decoder's gradients are final once its backward (main stream) and its weight gradients (side
+        stream) are done, so its clip + Adam + re-pack run on a third stream under the encoder's backward."""
+        main = torch.cuda.current_stream(self.device)
+        os_ = layers.opt_stream(self.device)
+        ev_main, ev_side = torch.cuda.Event(), torch.cuda.Event()
+        ev_main.record(main)
+        ev_side.record(layers.side_stream(self.device)['stream'])
+        os_.wait_event(ev_main)
+        os_.wait_event(ev_side)
+        with torch.cuda.stream(os_):
+            self._net_device_update('dec', self.Decoder)
+        self._dec_updated = True
+
     def _optimizer_device_step(self):
         """clip + Adam with the step count read from device memory, then re-pack the GEMM operands."""
-        self.grad_norms()
-        b1, b2 = self.betas
-        st = torch.cuda.current_stream(self.device).cuda_stream
-        for name, net in (('enc', self.Encoder), ('dec', self.Decoder)):
-            o = self._opt[name]
-            flat, gflat = net.flat_params()
-            L.call('zs_adam_clip', 'ZsAdam', st, p=L.ptr(flat), g=L.ptr(gflat), m=L.ptr(o['m']), v=L.ptr(o['v']),
-                   n=flat.numel(), lr=self.lr, beta1=b1, beta2=b2, eps=1e-8, bc1=1.0, bc2=1.0, sumsq=L.ptr(o['sq']),
-                   max_norm=self.max_grad_norm, write_clipped_grad=0, step_ptr=L.ptr(self._step_dev))
-            net.repack()
+        if getattr(self, '_dec_updated', False):
+            self._net_device_update('enc', self.Encoder)
+            ev = torch.cuda.Event()
+            ev.record(layers.opt_stream(self.device))
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            self._dec_updated = False
+        else:
+            self._net_device_update('enc', self.Encoder)
+            self._net_device_update('dec', self.Decoder)
         self.adam_step += 1
 
     def _graph_step(self, x_btf, c, multi):
@@ -168,6 +198,8 @@ class AEStep(object):
             self._seg_forward_decbwd(xs, cs, None, 2, None, parallel.rank(), st_ptr)
             if multi:
                 join_side(self.device)
+            elif self.early_dec_update:
+                self._early_decoder_update()
 
         def seg3():
             self._optimizer_device_step()
