@@ -76,7 +76,7 @@ def _ref_conv(x_btc, w, b, stride, reflect):
 
 
 GEMM_KEYS = ('gemm_dma', 'gemm_ring', 'gemm_ring_min_tiles', 'gemm_pp', 'gemm_p8', 'gemm_p8_min_tiles', 'wgrad_p8')
-GEMM_VARIANTS = {'p8': (1, 1, 1, 1, 1, 1, 2), 'pp': (1, 1, 1, 1, 0, 200, 0), 'ring': (1, 1, 1, 0, 0, 200, 0),
+GEMM_VARIANTS = {'p8': (1, 1, 1, 1, 1, 1, 2), 'p8m16': (1, 1, 1, 1, 2, 1, 0), 'pp': (1, 1, 1, 1, 0, 200, 0), 'ring': (1, 1, 1, 0, 0, 200, 0),
                  'dma': (1, 0, 256, 0, 0, 200, 0), 'reg': (0, 0, 256, 0, 0, 200, 0)}
 
 

@@ -16,7 +16,8 @@ ap.add_argument('--B', type=int, default=256); ap.add_argument('--T', type=int, 
 ap.add_argument('--cin', type=int, default=1024); ap.add_argument('--cout', type=int, default=2048)
 ap.add_argument('--k', type=int, default=3); ap.add_argument('--dtype', default='bf16')
 ap.add_argument('--iters', type=int, default=20); ap.add_argument('--mode', default='fwd')
-ap.add_argument('--variants', default='p8,pp,dma')
+ap.add_argument('--variants', default='p8m16,p8,dma')
+ap.add_argument('--rounds', type=int, default=5)
 ap.add_argument('--fill', default='normal', help='normal | zeros | ones: operand values (MFMA power depends on bit toggling)')
 a = ap.parse_args()
 os.environ['ZS_OVERLAP_WGRAD'] = '0'      # time the weight gradient on the stream the events are recorded on
@@ -70,12 +71,24 @@ def timed():
 
 
 fl = 2.0 * a.B * a.T * a.cout * a.cin * a.k
-VARIANTS = {'p8': (1, 1, 1, 1, 1, 1), 'pp': (1, 1, 1, 1, 0, 200), 'ring': (1, 1, 1, 0, 0, 200), 'dma': (1, 0, 256, 0, 0, 200), 'reg': (0, 0, 256, 0, 0, 200)}
-for name in (a.variants.split(',') if a.mode != 'wgrad' else ['p8', 't128']):
+VARIANTS = {'p8': (1, 1, 1, 1, 1, 1), 'p8m16': (1, 1, 1, 1, 2, 1), 'pp': (1, 1, 1, 1, 0, 200), 'ring': (1, 1, 1, 0, 0, 200), 'dma': (1, 0, 256, 0, 0, 200), 'reg': (0, 0, 256, 0, 0, 200)}
+names = a.variants.split(',') if a.mode != 'wgrad' else ['p8', 't128']
+
+
+def select(name):
     if a.mode == 'wgrad':
         L.set_option('wgrad_p8', 1 if name == 'p8' else 0)
     else:
         for k, v in zip(('gemm_dma', 'gemm_ring', 'gemm_ring_min_tiles', 'gemm_pp', 'gemm_p8', 'gemm_p8_min_tiles'), VARIANTS[name]):
             L.set_option(k, v)
-    ms = timed()
-    print('%s %s %-4s %s B%d T%d cin%d cout%d k%d: %.3f ms  %.1f TFLOP/s' % (a.mode, a.dtype, name, a.fill, a.B, a.T, a.cin, a.cout, a.k, ms, fl / ms / 1e9), flush=True)
+
+
+# interleaved rounds (A B C A B C ...): the chip is power-capped, so a variant measured first / on a cool chip reads high
+res = {n: [] for n in names}
+for rnd in range(a.rounds):
+    for n in names:
+        select(n)
+        res[n].append(timed())
+for n in names:
+    ms = sorted(res[n])[len(res[n]) // 2]
+    print('%s %s %-5s %s B%d T%d cin%d cout%d k%d: %.3f ms  %.1f TFLOP/s  (median of %d interleaved rounds)' % (a.mode, a.dtype, n, a.fill, a.B, a.T, a.cin, a.cout, a.k, ms, fl / ms / 1e9, a.rounds), flush=True)
