@@ -98,8 +98,16 @@ def cpu_baseline(seg_len, F, E, ch, nspk, steps=3, batch=16):
             'sample': '%d train_ae steps of %d x %d-frame segments (full-size model, fp32), median %.3f s/step' % (steps, batch, seg_len, med)}
 
 
+def _p8_dispatch(M, N, n_pad):
+    """zs_gemm_conv's rule for its 256x256 ping-pong kernel (csrc/zs_gemm.hip, default options)."""
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    return n_pad % 256 == 0 and tiles >= 200
+
+
 class KernelEvents(object):
-    """HIP-event timing of every gemm_conv launch made through ConvLayer.fwd / ConvLayer.dgrad."""
+    """HIP-event timing, on the launch stream, of every zs_gemm_conv launch made through ConvLayer.fwd / ConvLayer.dgrad that
+    dispatches to the dominant kernel (gemm_conv_p8m16_kernel: the 256x256 ping-pong tile); the smaller layers go to the
+    ring / 128x128 kernels and are not counted."""
 
     def __init__(self):
         self.pairs = []      # (start, end, flops)
@@ -111,7 +119,7 @@ class KernelEvents(object):
         ofwd, odgrad = layers.ConvLayer.fwd, layers.ConvLayer.dgrad
 
         def fwd(self, A, *a, **kw):
-            if not ke.enabled:
+            if not ke.enabled or not _p8_dispatch(A.B * self.t_out(A.T), self.Cout, self.n_pad):
                 return ofwd(self, A, *a, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -121,7 +129,7 @@ class KernelEvents(object):
             return r
 
         def dgrad(self, dY, T_x, out, *a, **kw):
-            if not ke.enabled:
+            if not ke.enabled or not _p8_dispatch(dY.B * (T_x + self.pad_l + self.pad_r), self.Cin, self.n_pad_d):
                 return odgrad(self, dY, T_x, out, *a, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -240,7 +248,7 @@ def main():
         fl, ms, n = ke.summary()
         ach = fl / (ms * 1e-3) / 1e12
         out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic, 'traffic_unit': 'bytes/launch',
-                           'kernel': 'zs_gemm_conv launches (gemm_conv_p8/ring/dma_kernel<%s>)' % ('bf16' if args.dtype == 'bf16' else 'float'),
+                           'kernel': 'gemm_conv_p8m16_kernel<%s> (zs_gemm_conv launches with >= 200 tiles of 256x256)' % ('bf16' if args.dtype == 'bf16' else 'float'),
                            'launches_timed': n, 'avg_launch_ms': ms / n, 'avg_launch_gflop': fl / n / 1e9,
                            'measured_on': ('instrumented eager steps after the timed region' if ae.use_graph else 'the timed steps')}
     else:

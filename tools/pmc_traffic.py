@@ -39,9 +39,9 @@ for k in sorted(f, key=lambda k: -f[k][1]):
     out['kernels'][k] = {'launches': n, 'fetch_bytes_per_launch_corrected': fb / n, 'write_bytes_per_launch': wb / max(1, w.get(k, [1])[0]),
                          'traffic_bytes_per_launch': fb / n + wb / max(1, w.get(k, [1])[0])}
 out['whole_run_gb'] = {'fetch_corrected': tot_f / 1e9, 'write': tot_w / 1e9}
-dom = 'gemm_conv_p8_kernel<unsigned short>'
+dom = 'gemm_conv_p8m16_kernel<unsigned short>'
 if dom in out['kernels']:
-    out['kernel'] = 'gemm_conv_p8_kernel<bf16>'
+    out['kernel'] = 'gemm_conv_p8m16_kernel<bf16>'
     out['traffic_bytes_per_launch'] = out['kernels'][dom]['traffic_bytes_per_launch']
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
 for k, v in list(out['kernels'].items())[:12]:
