@@ -1,21 +1,25 @@
 // zs_gemm.hip -- MFMA implicit-GEMM Conv1d / Linear (forward + data gradient) and weight gradient.
 //
 // gfx950 design notes
-//  * 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each 64x64 = 2x2 MFMA 32x32 tiles,
-//    64 fp32 accumulators/lane).  K is consumed in 128-byte chunks per row (64 bf16 / 32 fp32).
+//  * Four conv-GEMM kernels share one operand layout (channels-last activation rows, weights packed [n][tap][cin_pad],
+//    K consumed in 128-byte chunks per row) and one epilogue; zs_gemm_conv picks by problem size:
+//      gemm_conv_p8m16_kernel / gemm_conv_p8_kernel   256x256 tile, quadrant ping-pong, LDS-DMA half-tiles (>= 200 tiles)
+//      gemm_conv_ring_kernel                            256x128 tile, 3-stage LDS-DMA ring (>= 256 tiles)
+//      gemm_conv_dma_kernel                             128x128 tile, LDS-DMA double buffer (default for small layers)
+//      gemm_conv_kernel                                 128x128 tile, register-staged (reference variant, ZS_GEMM_DMA=0)
+//    and two weight-gradient kernels (gemm_wgrad_p8_kernel bf16 256x256 ping-pong, gemm_wgrad_kernel 128x128).
+//  * The MI355X is power-capped (1400 W) in these kernels, not issue-bound: what counts is bytes moved per FLOP and the
+//    MFMA shape (16x16x32 is the cheaper instruction), see DESIGN.md section 7.
 //  * Operand rows are whole channels-last activation rows, so the conv "im2col" is a per-row pointer
 //    computation (tap shift, reflect / zero padding, stride, transposed-conv validity) done by the
-//    loader threads only when the tap changes -- no padded copy of the activation is ever made
+//    loader lanes only when the tap changes -- no padded copy of the activation is ever made
 //    (the reference does F.pad + conv, model/model.py:36-39).
-//  * Register staging (global_load_dwordx4 -> ds_write_b128), double-buffered LDS, one barrier per
-//    K chunk; loads for chunk k+1 are issued before the MFMAs of chunk k (issue-early/write-late).
-//  * LDS rows are padded to 144 B: the 16 rows a ds_read_b128 lane group touches fall on 16 distinct
-//    16-byte slots of the 256-byte bank row (9*r mod 16 is a bijection), so fragment reads are
-//    conflict free; one ds_read_b128 feeds one v_mfma_f32_32x32x16_bf16 (bf16) or four
-//    v_mfma_f32_32x32x2_f32 (exact fp32; lane h supplies k = 4h+q in step q on both operands).
-//  * Accumulator layout (32x32): col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); lanes run
-//    along the output channel, so each store instruction writes 32 consecutive channels of a row.
-//  * blockIdx -> tile map is XCD-aware (consecutive tiles of one M panel share an XCD's L2).
+//  * LDS rows are 128 B with an XOR swizzle applied on the source side of the LDS-DMA (slot s' of row r holds
+//    segment s' ^ ((r>>1)&7)); the register-staged kernel pads rows to 144 B instead.  Either way the 16 rows a
+//    ds_read_b128 lane group touches fall on 16 distinct 16-byte slots of the 256-byte bank row.
+//  * Accumulator layouts: 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); 16x16: col = lane&15,
+//    row = 4*(lane>>4) + reg.  Lanes run along the output channel; the epilogue restages through LDS for 16-byte stores.
+//  * blockIdx -> tile maps are XCD-aware (tiles that share operand panels get the same XCD's L2).
 #include <stdlib.h>
 
 #include "zs_common.h"
