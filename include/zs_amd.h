@@ -47,8 +47,9 @@ const char* zs_last_error(void);
  *       packed weight has a multiple of 256 rows and the problem has at least that many 256x256 tiles
  *   "wgrad_p8" (ZS_WGRAD_P8, 1): 256x256 ping-pong weight-gradient kernel (bf16) where its heuristics accept the shape;
  *       0 = always the 128x128 kernel, 2 = whenever bf16 (tests)
- *   "gru_persist" (ZS_GRU_PERSIST, 0): 1 = one persistent launch per GRU forward pass (time loop on the device) when the
- *       grid fits one workgroup per CU (measured slower than one launch per time step: off by default)
+ *   "gru_persist" (ZS_GRU_PERSIST, 1): one persistent launch per GRU pass (forward and BPTT: the time loop runs on the
+ *       device, W_hh stays in registers, h / dgh travel between workgroups as data-tagged 8-byte granules) when the grid fits
+ *       one workgroup per CU and H allows it; 0 = one launch per time step
  * Returns the previous value, or ZS_EINVAL for an unknown key. */
 int zs_set_option(const char* key, int value);
 
@@ -254,6 +255,8 @@ int zs_mbv_bwd(const ZsMbvBwd* p, void* stream);
  * ([B*T][ldgi], columns dir*3H + {r,z,n}*H) comes from zs_gemm_conv.  Per time step the library
  * enqueues one grouped recurrent product (zs_gemm_conv kernel, 2 directions) and one gate kernel.
  * out[b,t, out_col + dir*H + j] = h_t.  gates saves r,z,n,(W_hn h + b_hn) for backward.
+ * Persistent path (default when (H/32)*ceil(B/32)*2 <= #CUs and H is a multiple of 128 (bf16) / 64 (fp32), H <= 512 /
+ * 256): ONE launch per pass, see gru_persist_fwd_kernel; needs the interleaved packing below.
  * Fast path (H % 32 == 0 and whh_interleaved): ONE launch per step -- a 16-rows-per-wave MFMA product whose
  * fragments come straight from L2 (no LDS, no barrier) with the gate math fused in its epilogue.  It needs the
  * rows of whh packed gate-interleaved per 32 hidden units: row hc*96 + g*32 + u = W_hh[g*H + hc*32 + u].

@@ -333,17 +333,16 @@ __global__ __launch_bounds__(256) void rowblock_gemm_kernel(const RowGemmArgs a)
 // only reads h_{t-1} of its 32 rows (written one step earlier by the H/32 workgroups of the same (rb, dir) group), runs
 // the MFMAs, reduces over the 4 waves through LDS, does the gate math for its (row, unit) elements (h_prev stays in a
 // register) and publishes its 32x32 slice of h_t.
-// Hand-off between the workgroups of a group (cdna guide, inter-workgroup communication):
-//   producer: h_t stored write-through (relaxed agent-scope atomic stores = sc1) -> every wave s_waitcnt vmcnt(0) ->
-//             __syncthreads -> one lane adds 1 to the group's arrival counter (agent-scope atomic)
-//   consumer: one lane polls the counter (relaxed agent-scope loads, s_sleep) until it reaches (H/32)*s -> barrier ->
-//             h_{t-1} fragments are read with agent-scope (sc1) loads, which bypass this CU's L1: no acquire fence.
-// Spins are bounded: on timeout the error word is set and the workgroup stops waiting (results are then wrong, never a
-// hang).  The whole grid (<= one workgroup per CU) must be able to be resident: checked on the host.
-// MEASURED (MI355X, B=256 T=128 H=512 bf16): 13.7 us per step against 11.1 us for one launch per step -- the
-// store-drain -> counter -> poll -> write-through re-read chain costs more than a kernel boundary (1.5-1.9 us) plus an
-// L2-resident re-read of W_hh -- so the option "gru_persist" is OFF by default and the kernel is kept as the tested
-// starting point for a data-tagged (flag-less) hand-off.
+// Hand-off between the workgroups of a group: DATA-TAGGED GRANULES, no flag, no fence, no drain (cdna guide, recipe R2).
+// h travels through an exchange buffer hx[dir][step parity][row][granule] of naturally aligned 8-byte words
+// {payload: 4 bytes of h (2 bf16 / 1 fp32), tag: step + 1}, each written by ONE agent-scope (sc1, write-through) store.
+// A consumer wave sweeps the granules of its own MFMA fragments with sc1 loads (they bypass this CU's L1) until every
+// tag equals the step it needs; the payloads ARE the fragment.  Two parities suffice: nobody can write h_{s+1} before
+// every workgroup of the group has published h_s, i.e. has finished reading h_{s-1}.  hx is zeroed before every launch
+// (tags of an earlier call must not match).  Spins are bounded: on timeout the error word is set and the wave stops
+// waiting (results are then wrong, never a hang).  The whole grid (<= one workgroup per CU) is co-resident: host check.
+// An earlier version with write-through payload + arrival counter + poll measured 13.7 us per step against 11.1 us for
+// one launch per step (the drain -> counter -> poll -> re-read chain is longer than a kernel boundary).
 // ------------------------------------------------------------------------------------------------
 struct GruPersistArgs {
   const void* gi; int64_t ldgi;
@@ -351,22 +350,19 @@ struct GruPersistArgs {
   const float* bhh; int64_t bhh_gstride;
   void* out; int64_t ldo; int out_col;
   void* gates;
-  unsigned* cnt;                 // [2][nrb] arrival counters + error word at [2*nrb]; zeroed before the launch
-  int B, T, H, nrb;
-  // backward only
-  const void* dout; int64_t ldd; int dout_col;
-  void* dgi; int64_t ldgi_b;
-  void* dgh; int64_t ldgh;
+  unsigned long long* hx;        // exchange granules [2 dirs][2 parities][rows_pad][gpr]; zeroed before the launch
+  unsigned* err;                 // error word (behind hx), zeroed with it
+  int B, T, H, rows_pad;
 };
 
-typedef __attribute__((address_space(1))) unsigned long long gu64_t;
-typedef __attribute__((address_space(1))) unsigned gu32_t;
-
-// 16-byte agent-scope (sc1: bypasses this CU's L1) load.  Inline asm so that all fragment loads of a step are in flight
-// together (hipcc issues relaxed atomic loads one at a time, each behind a wait); the caller waits with s_waitcnt vmcnt(0).
+// 16-byte agent-scope (sc1: bypasses this CU's L1) load.  Inline asm so that all loads of a sweep are in flight together
+// (hipcc issues relaxed atomic loads one at a time, each behind a wait); the caller waits with s_waitcnt vmcnt(0).
 typedef __attribute__((ext_vector_type(4))) unsigned gu32x4_t;
 __device__ __forceinline__ void load16_sc1_issue(gu32x4_t& dst, const void* p) {
   asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void store_granule(unsigned long long* g, unsigned tag, unsigned payload) {
+  __hip_atomic_store(g, ((unsigned long long)tag << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <typename T> struct Pair;
 template <> struct Pair<bf16_t> {
@@ -376,57 +372,35 @@ template <> struct Pair<bf16_t> {
   }
   static __device__ __forceinline__ unsigned pack(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
   static __device__ __forceinline__ void st(bf16_t* p, float a, float b) { *reinterpret_cast<unsigned*>(p) = pack(a, b); }
-  static __device__ __forceinline__ void st_sc1(bf16_t* p, float a, float b) {
-    __hip_atomic_store(reinterpret_cast<unsigned*>(p), pack(a, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // the pair (unit j, j+1) of a row is ONE granule
+  static __device__ __forceinline__ void publish(unsigned long long* row, int j, unsigned tag, float a, float b) {
+    store_granule(row + (j >> 1), tag, pack(a, b));
   }
-  // what the consumer will read back (rounded to T)
-  static __device__ __forceinline__ float rnd(float a) { return bf2f(f2bf(a)); }
 };
 template <> struct Pair<float> {
   static __device__ __forceinline__ void ld(const float* p, float& a, float& b) { const float2 v = *reinterpret_cast<const float2*>(p); a = v.x; b = v.y; }
   static __device__ __forceinline__ void st(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
-  static __device__ __forceinline__ void st_sc1(float* p, float a, float b) {
-    const unsigned long long w = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  static __device__ __forceinline__ void publish(unsigned long long* row, int j, unsigned tag, float a, float b) {
+    store_granule(row + j, tag, __float_as_uint(a));
+    store_granule(row + j + 1, tag, __float_as_uint(b));
   }
-  static __device__ __forceinline__ float rnd(float a) { return a; }
 };
 
-constexpr unsigned GRU_SPIN_LIMIT = 1u << 22;
-
-// wait until the group's counter reaches `want` (one lane polls; everyone leaves through the barrier)
-__device__ __forceinline__ void gru_group_wait(unsigned* cnt, unsigned* err, unsigned want, int tid) {
-  if (tid == 0) {
-    unsigned spins = 0;
-    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > GRU_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-    }
-  }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // compiler: keep the h loads below the poll
-}
-__device__ __forceinline__ void gru_group_arrive(unsigned* cnt, int tid) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every storing wave drains its write-through stores
-  __syncthreads();
-  if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+constexpr unsigned GRU_SPIN_LIMIT = 1u << 21;
 
 template <typename T, int PER>     // PER = k-steps (of Frag16<T>::KSTEP) per wave: H = 4 * PER * KSTEP
 __global__ __launch_bounds__(256) void gru_persist_fwd_kernel(const GruPersistArgs a) {
   constexpr int KSTEP = Frag16<T>::KSTEP;
   constexpr int EPL = 16 / (int)sizeof(T);
+  constexpr int GPE = 4 / (int)sizeof(T);              // elements per granule payload
   __shared__ float part[4][RB][6][4][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, r = lane & 15;
   const int d = blockIdx.z, H = a.H, T_ = a.T;
   const int m0 = blockIdx.y * 16 * RB;
-  unsigned* cnt = a.cnt + d * a.nrb + blockIdx.y;
-  unsigned* err = a.cnt + 2 * a.nrb;
-  const unsigned group = (unsigned)(H / 32);
+  const int gpr = H / GPE;                             // granules per row
+  const int64_t par_stride = (int64_t)a.rows_pad * gpr;
+  unsigned long long* hx_d = a.hx + (int64_t)d * 2 * par_stride;
 
   // W_hh slice of this workgroup, this wave's K quarter: registers for the whole sequence
   uint4 fb[PER][6];
@@ -437,14 +411,14 @@ __global__ __launch_bounds__(256) void gru_persist_fwd_kernel(const GruPersistAr
 #pragma unroll
       for (int c = 0; c < 6; ++c) fb[u][c] = *reinterpret_cast<const uint4*>(Wrow + (int64_t)(16 * c) * a.ldw + (wave * PER + u) * KSTEP);
   }
-  // A rows of the fragments
-  const T* Abase[RB];
+  // fragment granules of this lane: row m0 + 16 rb + r, elements (wave*PER + u)*KSTEP + q*EPL .. +EPL-1 = 4 granules
+  const unsigned long long* Ag[RB];
   bool rvalid[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     const int row = m0 + 16 * rb + r;
     rvalid[rb] = row < a.B;
-    Abase[rb] = (const T*)a.out + (int64_t)(rvalid[rb] ? row : 0) * T_ * a.ldo + a.out_col + d * H + q * EPL + wave * PER * KSTEP;
+    Ag[rb] = hx_d + (int64_t)row * gpr + (q * EPL + wave * PER * KSTEP) / GPE;
   }
   // epilogue ownership: unit pair (2*eu2, 2*eu2+1) of the 32 units, rows e_row + 16*pz
   const int eu2 = tid & 15, e_row = tid >> 4;
@@ -453,10 +427,11 @@ __global__ __launch_bounds__(256) void gru_persist_fwd_kernel(const GruPersistAr
   const float* bh = a.bhh + (int64_t)d * a.bhh_gstride;
   const float b_r0 = bh[j], b_r1 = bh[j + 1], b_z0 = bh[H + j], b_z1 = bh[H + j + 1], b_n0 = bh[2 * H + j], b_n1 = bh[2 * H + j + 1];
   float hp[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  bool dead = false;                                   // a sweep timed out: stop waiting (wave-uniform)
 
   for (int s = 0; s < T_; ++s) {
     const int t = d == 0 ? s : T_ - 1 - s;
-    // gate inputs of this step do not depend on other workgroups: issue them before the wait
+    // gate inputs of this step do not depend on other workgroups: issue them before the sweep
     float gi_r[2][2], gi_z[2][2], gi_n[2][2];
 #pragma unroll
     for (int pz = 0; pz < 2; ++pz) {
@@ -473,24 +448,43 @@ __global__ __launch_bounds__(256) void gru_persist_fwd_kernel(const GruPersistAr
 #pragma unroll
       for (int c = 0; c < 6; ++c) acc[rb][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
-      gru_group_wait(cnt, err, group * (unsigned)s, tid);
-      const int tp = d == 0 ? t - 1 : t + 1;
-      gu32x4_t fr[PER][RB];
+      // sweep the granules of h_{s-1} (tag s, parity (s-1)&1) until every tag of this wave's fragments matches
+      const int64_t poff = (int64_t)((s - 1) & 1) * par_stride;
+      gu32x4_t g0[PER][RB], g1[PER][RB];
+      unsigned spins = 0;
+      for (;;) {
 #pragma unroll
-      for (int u = 0; u < PER; ++u)
+        for (int u = 0; u < PER; ++u)
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) load16_sc1_issue(fr[u][rb], Abase[rb] + (int64_t)tp * a.ldo + u * KSTEP);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);             // nothing that reads fr[][] may be scheduled above the wait
+          for (int rb = 0; rb < RB; ++rb) {
+            const unsigned long long* gp = Ag[rb] + poff + (u * KSTEP) / GPE;
+            load16_sc1_issue(g0[u][rb], gp);
+            load16_sc1_issue(g1[u][rb], gp + 2);
+          }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);             // nothing that reads the granules may be scheduled above the wait
+        bool ok = true;
 #pragma unroll
-      for (int u = 0; u < PER; ++u)
+        for (int u = 0; u < PER; ++u)
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) asm volatile("" : "+v"(fr[u][rb]));    // ... and the values are defined only from here on
+          for (int rb = 0; rb < RB; ++rb) {
+            asm volatile("" : "+v"(g0[u][rb]), "+v"(g1[u][rb]));       // the values are defined only from here on
+            const bool m = (g0[u][rb].y == (unsigned)s) & (g0[u][rb].w == (unsigned)s) & (g1[u][rb].y == (unsigned)s) & (g1[u][rb].w == (unsigned)s);
+            ok &= (m | !rvalid[rb]);
+          }
+        if (__all(ok) || dead) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > GRU_SPIN_LIMIT) {
+          if (lane == 0) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          dead = true;
+          break;
+        }
+      }
 #pragma unroll
       for (int u = 0; u < PER; ++u)
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-          uint4 fa = make_uint4(fr[u][rb].x, fr[u][rb].y, fr[u][rb].z, fr[u][rb].w);
+          uint4 fa = make_uint4(g0[u][rb].x, g0[u][rb].z, g1[u][rb].x, g1[u][rb].z);
           if (!rvalid[rb]) fa = make_uint4(0, 0, 0, 0);
 #pragma unroll
           for (int c = 0; c < 6; ++c) Frag16<T>::mma(fa, fb[u][c], acc[rb][c]);
@@ -507,6 +501,7 @@ __global__ __launch_bounds__(256) void gru_persist_fwd_kernel(const GruPersistAr
       const int rb = rr >> 4, l = ((rr & 15) >> 2) * 16 + col, i = rr & 3;
       return (part[0][rb][c][i][l] + part[1][rb][c][i][l]) + (part[2][rb][c][i][l] + part[3][rb][c][i][l]);
     };
+    unsigned long long* hx_w = hx_d + (int64_t)(s & 1) * par_stride;
 #pragma unroll
     for (int pz = 0; pz < 2; ++pz) {
       const int rr = e_row + 16 * pz;
@@ -523,14 +518,185 @@ __global__ __launch_bounds__(256) void gru_persist_fwd_kernel(const GruPersistAr
           hv[e] = (1.f - zg[e]) * ng[e] + zg[e] * hp[pz][e];
           hp[pz][e] = hv[e];
         }
-        Pair<T>::st_sc1((T*)a.out + ((int64_t)b * T_ + t) * a.ldo + a.out_col + d * H + j, hv[0], hv[1]);
+        if (s + 1 < T_) Pair<T>::publish(hx_w + (int64_t)b * gpr, j, (unsigned)(s + 1), hv[0], hv[1]);    // first: the others wait for it
+        Pair<T>::st((T*)a.out + ((int64_t)b * T_ + t) * a.ldo + a.out_col + d * H + j, hv[0], hv[1]);
         if (a.gates) {
           T* gs = (T*)a.gates + (((int64_t)b * T_ + t) * 2 + d) * 4 * H + j;
           Pair<T>::st(gs, rg[0], rg[1]); Pair<T>::st(gs + H, zg[0], zg[1]); Pair<T>::st(gs + 2 * H, ng[0], ng[1]); Pair<T>::st(gs + 3 * H, hn[0], hn[1]);
         }
       }
     }
-    if (s + 1 < T_) gru_group_arrive(cnt, tid);      // also the barrier that frees `part` for the next step
+    __syncthreads();                                   // `part` is free for the next step
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent BPTT, same hand-off: workgroup (hc, rb, dir) owns 32 hidden units x 32 rows.  Per step it needs dgh of the
+// previous BPTT step for its rows and ALL 3H gate columns (published by the H/32 workgroups of its group as granules),
+// multiplies by its 32 rows of W_hh^T (32 x 3H, register-resident: each wave keeps its quarter of K), adds dout and its
+// own direct carry dh*z (a register) and runs the gate backward for its (row, unit) elements.
+// ------------------------------------------------------------------------------------------------
+struct GruPersistBwdArgs {
+  const void* dout; int64_t ldd; int dout_col;
+  const void* out; int64_t ldo; int out_col;
+  const void* gates;
+  const void* whh_t; int64_t ldw; int64_t w_gstride;
+  void* dgi; int64_t ldgi;
+  void* dgh; int64_t ldgh;
+  unsigned long long* dx;        // exchange granules [2 dirs][2 parities][rows_pad][3H / GPE]; zeroed before the launch
+  unsigned* err;
+  int B, T, H, rows_pad;
+};
+
+template <typename T, int PERB>    // PERB = k-steps per wave: 3H = 4 * PERB * KSTEP
+__global__ __launch_bounds__(256) void gru_persist_bwd_kernel(const GruPersistBwdArgs a) {
+  constexpr int KSTEP = Frag16<T>::KSTEP;
+  constexpr int EPL = 16 / (int)sizeof(T);
+  constexpr int GPE = 4 / (int)sizeof(T);
+  __shared__ float part[4][RB][2][4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, r = lane & 15;
+  const int d = blockIdx.z, H = a.H, T_ = a.T;
+  const int m0 = blockIdx.y * 16 * RB;
+  const int gpr = 3 * H / GPE;
+  const int64_t par_stride = (int64_t)a.rows_pad * gpr;
+  unsigned long long* dx_d = a.dx + (int64_t)d * 2 * par_stride;
+
+  uint4 fb[PERB][2];
+  {
+    const T* Wrow = (const T*)a.whh_t + (int64_t)d * a.w_gstride + (int64_t)(blockIdx.x * 32 + r) * a.ldw + q * EPL;
+#pragma unroll
+    for (int u = 0; u < PERB; ++u)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) fb[u][c] = *reinterpret_cast<const uint4*>(Wrow + (int64_t)(16 * c) * a.ldw + (wave * PERB + u) * KSTEP);
+  }
+  const unsigned long long* Ag[RB];
+  bool rvalid[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int row = m0 + 16 * rb + r;
+    rvalid[rb] = row < a.B;
+    Ag[rb] = dx_d + (int64_t)row * gpr + (q * EPL + wave * PERB * KSTEP) / GPE;
+  }
+  const int eu2 = tid & 15, e_row = tid >> 4;
+  const int j = blockIdx.x * 32 + 2 * eu2;
+  const int hh = (2 * eu2) >> 4, cc = (2 * eu2) & 15;
+  float dhd[2][2] = {{0.f, 0.f}, {0.f, 0.f}};          // direct carry dh * z of the previous BPTT step
+  bool dead = false;
+
+  for (int s = 0; s < T_; ++s) {
+    const int t = d == 0 ? T_ - 1 - s : s;              // reverse of the forward order
+    // operands of this step's gate math that no other workgroup writes in this launch: issue before the sweep
+    float w_r[2][2], w_z[2][2], w_n[2][2], w_hn[2][2], w_do[2][2], w_hp[2][2];
+#pragma unroll
+    for (int pz = 0; pz < 2; ++pz) {
+      const int b = m0 + e_row + 16 * pz;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) w_r[pz][e] = w_z[pz][e] = w_n[pz][e] = w_hn[pz][e] = w_do[pz][e] = w_hp[pz][e] = 0.f;
+      if (b < a.B) {
+        const int64_t row = (int64_t)b * T_ + t;
+        const T* gs = (const T*)a.gates + (row * 2 + d) * 4 * H + j;
+        Pair<T>::ld(gs, w_r[pz][0], w_r[pz][1]); Pair<T>::ld(gs + H, w_z[pz][0], w_z[pz][1]);
+        Pair<T>::ld(gs + 2 * H, w_n[pz][0], w_n[pz][1]); Pair<T>::ld(gs + 3 * H, w_hn[pz][0], w_hn[pz][1]);
+        Pair<T>::ld((const T*)a.dout + row * a.ldd + a.dout_col + d * H + j, w_do[pz][0], w_do[pz][1]);
+        if (s < T_ - 1) {
+          const int tp = d == 0 ? t - 1 : t + 1;
+          Pair<T>::ld((const T*)a.out + ((int64_t)b * T_ + tp) * a.ldo + a.out_col + d * H + j, w_hp[pz][0], w_hp[pz][1]);
+        }
+      }
+    }
+    f32x4_t acc[RB][2];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) acc[rb][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
+      const int64_t poff = (int64_t)((s - 1) & 1) * par_stride;
+      gu32x4_t g0[PERB][RB], g1[PERB][RB];
+      unsigned spins = 0;
+      for (;;) {
+#pragma unroll
+        for (int u = 0; u < PERB; ++u)
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) {
+            const unsigned long long* gp = Ag[rb] + poff + (u * KSTEP) / GPE;
+            load16_sc1_issue(g0[u][rb], gp);
+            load16_sc1_issue(g1[u][rb], gp + 2);
+          }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        bool ok = true;
+#pragma unroll
+        for (int u = 0; u < PERB; ++u)
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) {
+            asm volatile("" : "+v"(g0[u][rb]), "+v"(g1[u][rb]));
+            const bool m = (g0[u][rb].y == (unsigned)s) & (g0[u][rb].w == (unsigned)s) & (g1[u][rb].y == (unsigned)s) & (g1[u][rb].w == (unsigned)s);
+            ok &= (m | !rvalid[rb]);
+          }
+        if (__all(ok) || dead) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > GRU_SPIN_LIMIT) {
+          if (lane == 0) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          dead = true;
+          break;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < PERB; ++u)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          uint4 fa = make_uint4(g0[u][rb].x, g0[u][rb].z, g1[u][rb].x, g1[u][rb].z);
+          if (!rvalid[rb]) fa = make_uint4(0, 0, 0, 0);
+#pragma unroll
+          for (int c = 0; c < 2; ++c) Frag16<T>::mma(fa, fb[u][c], acc[rb][c]);
+        }
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[wave][rb][c][i][lane] = acc[rb][c][i];
+    __syncthreads();
+    auto total = [&](int c, int rr, int col) -> float {
+      const int rb = rr >> 4, l = ((rr & 15) >> 2) * 16 + col, i = rr & 3;
+      return (part[0][rb][c][i][l] + part[1][rb][c][i][l]) + (part[2][rb][c][i][l] + part[3][rb][c][i][l]);
+    };
+    unsigned long long* dx_w = dx_d + (int64_t)(s & 1) * par_stride;
+#pragma unroll
+    for (int pz = 0; pz < 2; ++pz) {
+      const int rr = e_row + 16 * pz;
+      const int b = m0 + rr;
+      if (b < a.B) {
+        float dr_pre[2], dz_pre[2], dn_pre[2], dnr[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float dh = w_do[pz][e] + dhd[pz][e];
+          if (s > 0) dh += total(hh, rr, cc + e);
+          const float r_ = w_r[pz][e], z_ = w_z[pz][e], n_ = w_n[pz][e];
+          const float dn = dh * (1.f - z_);
+          const float dz = dh * (w_hp[pz][e] - n_);
+          dhd[pz][e] = dh * z_;
+          dn_pre[e] = dn * (1.f - n_ * n_);
+          dr_pre[e] = dn_pre[e] * w_hn[pz][e] * r_ * (1.f - r_);
+          dz_pre[e] = dz * z_ * (1.f - z_);
+          dnr[e] = dn_pre[e] * r_;
+        }
+        if (s + 1 < T_) {                              // first: the group waits for these
+          unsigned long long* xr = dx_w + (int64_t)b * gpr;
+          Pair<T>::publish(xr, j, (unsigned)(s + 1), dr_pre[0], dr_pre[1]);
+          Pair<T>::publish(xr, H + j, (unsigned)(s + 1), dz_pre[0], dz_pre[1]);
+          Pair<T>::publish(xr, 2 * H + j, (unsigned)(s + 1), dnr[0], dnr[1]);
+        }
+        const int64_t row = (int64_t)b * T_ + t;
+        T* gi = (T*)a.dgi + row * a.ldgi + (int64_t)d * 3 * H + j;
+        T* gh = (T*)a.dgh + row * a.ldgh + (int64_t)d * 3 * H + j;
+        Pair<T>::st(gi, dr_pre[0], dr_pre[1]); Pair<T>::st(gi + H, dz_pre[0], dz_pre[1]); Pair<T>::st(gi + 2 * H, dn_pre[0], dn_pre[1]);
+        Pair<T>::st(gh, dr_pre[0], dr_pre[1]); Pair<T>::st(gh + H, dz_pre[0], dz_pre[1]); Pair<T>::st(gh + 2 * H, dnr[0], dnr[1]);
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -540,9 +706,15 @@ inline unsigned gate_blocks(int64_t total) {
   return (unsigned)(b < 1 ? 1 : b);
 }
 
+// exchange granules of the persistent kernels: [2 dirs][2 parities][rows rounded to 32][cols * es / 4] x 8 bytes
+// (cols = H forward, 3H backward)
+size_t gru_hx_bytes(int B, int H, int es) {
+  const size_t rows = (size_t)((B + 16 * RB - 1) / (16 * RB)) * 16 * RB;
+  return (size_t)2 * 2 * rows * ((size_t)H * es / 4) * 8;
+}
 int g_gru_persist = -1;
 bool gru_persist_enabled() {
-  if (g_gru_persist < 0) { const char* e = getenv("ZS_GRU_PERSIST"); g_gru_persist = e ? atoi(e) : 0; }
+  if (g_gru_persist < 0) { const char* e = getenv("ZS_GRU_PERSIST"); g_gru_persist = e ? atoi(e) : 1; }
   return g_gru_persist != 0;
 }
 // workgroups that are certainly co-resident: one per CU
@@ -562,8 +734,10 @@ int64_t gru_resident_limit() {
 int zs_gru_persist_option(int value) { const int old = gru_persist_enabled() ? 1 : 0; g_gru_persist = value ? 1 : 0; return old; }
 
 extern "C" size_t zs_gru_work_bytes(int32_t B, int32_t H) {
-  // gh [2][B][3H] + hstate/dhd [2][B][H] + dhg [2][B][H], fp32
-  return (size_t)2 * (size_t)B * (size_t)(5 * H) * sizeof(float) + 256;
+  // gh [2][B][3H] + hstate/dhd [2][B][H] + dhg [2][B][H], fp32; or the persistent kernel's exchange granules (fp32 size) + error word
+  const size_t steps = (size_t)2 * (size_t)B * (size_t)(5 * H) * sizeof(float) + 256;
+  const size_t hx = gru_hx_bytes(B, 3 * H, 4) + 256;
+  return steps > hx ? steps : hx;
 }
 
 extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
@@ -584,14 +758,16 @@ extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
     const int kstep = p->dtype == ZS_F32 ? 16 : 32;
     const int per = (H % (4 * kstep) == 0) ? H / (4 * kstep) : 0;
     const int64_t nwg = (int64_t)(H / 32) * nrb * 2;
-    if (gru_persist_enabled() && (per == 1 || per == 2 || per == 4) && nwg <= gru_resident_limit() && 2 * nrb + 1 <= 64 && T > 1) {
+    if (gru_persist_enabled() && (per == 1 || per == 2 || per == 4) && nwg <= gru_resident_limit() && T > 1) {
       GruPersistArgs a;
       memset(&a, 0, sizeof(a));
       a.gi = p->gi; a.ldgi = p->ldgi; a.whh = p->whh; a.ldw = p->ldw; a.w_gstride = p->w_gstride;
       a.bhh = p->bhh; a.bhh_gstride = p->bhh_gstride; a.out = p->out; a.ldo = p->ldo; a.out_col = p->out_col; a.gates = p->gates;
-      a.cnt = reinterpret_cast<unsigned*>(p->work + (size_t)2 * B * 5 * H);     // the 256-byte tail of the work buffer
-      a.B = B; a.T = T; a.H = H; a.nrb = nrb;
-      if (hipMemsetAsync(a.cnt, 0, 256, (hipStream_t)stream) != hipSuccess) { zs_set_error("zs_gru_fwd: memset failed"); return ZS_ELAUNCH; }
+      const size_t hx_bytes = gru_hx_bytes(B, H, es);
+      a.hx = reinterpret_cast<unsigned long long*>(p->work);
+      a.err = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p->work) + hx_bytes);
+      a.B = B; a.T = T; a.H = H; a.rows_pad = nrb * 16 * RB;
+      if (hipMemsetAsync(p->work, 0, hx_bytes + 16, (hipStream_t)stream) != hipSuccess) { zs_set_error("zs_gru_fwd: memset failed"); return ZS_ELAUNCH; }
       dim3 grid(H / 32, nrb, 2);
 #define ZS_GRU_PF(TT, PP) hipLaunchKernelGGL((gru_persist_fwd_kernel<TT, PP>), grid, dim3(256), 0, (hipStream_t)stream, a)
       if (p->dtype == ZS_F32) { if (per == 1) ZS_GRU_PF(float, 1); else if (per == 2) ZS_GRU_PF(float, 2); else ZS_GRU_PF(float, 4); }
@@ -662,6 +838,30 @@ extern "C" int zs_gru_bwd(const ZsGruBwd* p, void* stream) {
   float* dhg = dhd + (size_t)2 * B * H;
   const char* dghb = (const char*)p->dgh;
   const bool fast = (H % 32 == 0);
+  if (fast && gru_persist_enabled() && T > 1) {
+    const int nrb = (B + 16 * RB - 1) / (16 * RB);
+    const int kstep = p->dtype == ZS_F32 ? 16 : 32;
+    const int perb = ((3 * H) % (4 * kstep) == 0) ? (3 * H) / (4 * kstep) : 0;
+    const int64_t nwg = (int64_t)(H / 32) * nrb * 2;
+    if ((perb == 3 || perb == 6 || perb == 12) && nwg <= gru_resident_limit()) {
+      GruPersistBwdArgs a;
+      memset(&a, 0, sizeof(a));
+      a.dout = p->dout; a.ldd = p->ldd; a.dout_col = p->dout_col; a.out = p->out; a.ldo = p->ldo; a.out_col = p->out_col;
+      a.gates = p->gates; a.whh_t = p->whh_t; a.ldw = p->ldw; a.w_gstride = p->w_gstride;
+      a.dgi = p->dgi; a.ldgi = p->ldgi; a.dgh = p->dgh; a.ldgh = p->ldgh;
+      const size_t dx_bytes = gru_hx_bytes(B, 3 * H, es);
+      a.dx = reinterpret_cast<unsigned long long*>(p->work);
+      a.err = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p->work) + dx_bytes);
+      a.B = B; a.T = T; a.H = H; a.rows_pad = nrb * 16 * RB;
+      if (hipMemsetAsync(p->work, 0, dx_bytes + 16, (hipStream_t)stream) != hipSuccess) { zs_set_error("zs_gru_bwd: memset failed"); return ZS_ELAUNCH; }
+      dim3 grid(H / 32, nrb, 2);
+#define ZS_GRU_PB(TT, PP) hipLaunchKernelGGL((gru_persist_bwd_kernel<TT, PP>), grid, dim3(256), 0, (hipStream_t)stream, a)
+      if (p->dtype == ZS_F32) { if (perb == 3) ZS_GRU_PB(float, 3); else if (perb == 6) ZS_GRU_PB(float, 6); else ZS_GRU_PB(float, 12); }
+      else { if (perb == 3) ZS_GRU_PB(bf16_t, 3); else if (perb == 6) ZS_GRU_PB(bf16_t, 6); else ZS_GRU_PB(bf16_t, 12); }
+#undef ZS_GRU_PB
+      return zs_check_launch("zs_gru_bwd.persist");
+    }
+  }
   for (int s = 0; s < T; ++s) {
     GateBwdArgs a;
     a.dout = p->dout; a.ldd = p->ldd; a.dout_col = p->dout_col; a.out = p->out; a.ldo = p->ldo; a.out_col = p->out_col;
