@@ -46,24 +46,38 @@ class Act(object):
 
 
 _SIDE = {}
+N_SIDE = max(1, int(os.environ.get('ZS_SIDE_STREAMS', '4')))
 
 
 def side_stream(device):
-    """One extra HIP stream per device for work that is off the critical path (weight gradients)."""
+    """Extra HIP streams per device for work that is off the critical path (weight gradients): N_SIDE streams used round
+    robin, so that the many small weight-gradient GEMMs (conv bank, T'=16 layers) run side by side instead of in a queue."""
     key = (device.type, device.index)
     if key not in _SIDE:
-        _SIDE[key] = {'stream': torch.cuda.Stream(device), 'used': False}
+        _SIDE[key] = {'streams': [torch.cuda.Stream(device) for _ in range(N_SIDE)], 'used': False, 'next': 0, 'ws': [None] * N_SIDE}
     return _SIDE[key]
 
 
+def side_events(device):
+    """One event per side stream, recorded now (everything enqueued on the side streams so far)."""
+    sd = side_stream(device)
+    evs = []
+    for st in sd['streams']:
+        ev = torch.cuda.Event()
+        ev.record(st)
+        evs.append(ev)
+    return evs
+
+
 def join_side(device):
-    """Make the current stream wait for everything enqueued on the side stream."""
+    """Make the current stream wait for everything enqueued on the side streams."""
     sd = side_stream(device)
     if sd['used']:
-        ev = torch.cuda.Event()
-        ev.record(sd['stream'])
-        torch.cuda.current_stream(device).wait_event(ev)
+        cur = torch.cuda.current_stream(device)
+        for ev in side_events(device):
+            cur.wait_event(ev)
         sd['used'] = False
+    sd['next'] = 0          # the same launch -> stream assignment every step (hipGraph capture replays exactly this)
 
 
 _OPT = {}
@@ -230,19 +244,31 @@ def wgrad_call(ctx, kw):
         if v is not None:
             setattr(s, k, v)
     need = L.lib().zs_gemm_wgrad_workspace_bytes(ctypes.byref(s))
-    ws = ctx.workspace(need)
-    s.workspace = ws.data_ptr()
-    s.workspace_bytes = ws.numel()
     stream = ctx.stream
     if ctx.overlap_wgrad:
         # ordered after everything enqueued so far on the main stream (dY and X are complete), then asynchronous;
-        # all weight gradients serialise on the side stream, so they can share the split-K workspace
+        # the weight gradients of one side stream serialise, so they share that stream's split-K workspace
         sd = side_stream(ctx.device)
+        i = sd['next']                                   # plain round robin (measured: 1 stream 13.7 ms/step, 3: 13.5, 4: 13.0,
+        sd['next'] = (i + 1) % len(sd['streams'])        # 8: 13.05; big GEMMs pinned to one stream: 13.55)
+        ws = sd['ws'][i]
+        if ws is None or ws.numel() < need:
+            # growth (first steps only): every side stream gets a workspace of the new size, so that no later launch --
+            # in particular none inside a hipGraph capture -- has to grow one
+            if any(w is not None for w in sd['ws']):
+                torch.cuda.synchronize(ctx.device)      # the streams may still be using the old buffers
+            size = int(need * 1.25) + 1024
+            sd['ws'] = [torch.empty(size, dtype=torch.uint8, device=ctx.device) for _ in sd['streams']]
+            ws = sd['ws'][i]
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(ctx.device))
-        sd['stream'].wait_event(ev)
+        sd['streams'][i].wait_event(ev)
         sd['used'] = True
-        stream = sd['stream'].cuda_stream
+        stream = sd['streams'][i].cuda_stream
+    else:
+        ws = ctx.workspace(need)
+    s.workspace = ws.data_ptr()
+    s.workspace_bytes = ws.numel()
     L.check(L.lib().zs_gemm_wgrad(ctypes.byref(s), ctypes.c_void_p(stream)), 'zs_gemm_wgrad')
 
 

@@ -137,11 +137,11 @@ class AEStep(object):
         stream) are done, so its clip + Adam + re-pack run on a third stream under the encoder's backward."""
         main = torch.cuda.current_stream(self.device)
         os_ = layers.opt_stream(self.device)
-        ev_main, ev_side = torch.cuda.Event(), torch.cuda.Event()
+        ev_main = torch.cuda.Event()
         ev_main.record(main)
-        ev_side.record(layers.side_stream(self.device)['stream'])
         os_.wait_event(ev_main)
-        os_.wait_event(ev_side)
+        for ev in layers.side_events(self.device):
+            os_.wait_event(ev)
         with torch.cuda.stream(os_):
             self._net_device_update('dec', self.Decoder)
         self._dec_updated = True
