@@ -104,6 +104,33 @@ def _p8_dispatch(M, N, n_pad):
     return n_pad % 256 == 0 and tiles >= 200
 
 
+def isolated_kernel_rate(dev, dtype, launches=200):
+    """The dominant kernel alone on the GPU: the decoder's largest conv (k3 1024 -> 2048 at T=64, M = 16384 rows), `launches`
+    back-to-back launches (~40 ms: long enough for the power-capped clocks to settle), HIP events on the launch stream."""
+    from zs_amd import _lib as L, layers
+    ctx = layers.Ctx(dev, dtype)
+    w = torch.randn(2048, 1024, 3, device=dev) * 0.02
+    b = torch.zeros(2048, device=dev)
+    l = layers.ConvLayer(ctx, w, b, torch.zeros_like(w), torch.zeros_like(b))
+    l.pack()
+    X = ctx.act('iso_x', 256, 64, 1024)
+    X.t.normal_()
+    Y = ctx.act('iso_y', 256, 64, 2048)
+    for _ in range(20):
+        l.fwd(X, out=Y, act=L.ZS_ACT_LRELU, slope=0.01)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(launches):
+        l.fwd(X, out=Y, act=L.ZS_ACT_LRELU, slope=0.01)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / launches
+    fl = 2.0 * 256 * 64 * 2048 * 1024 * 3
+    return {'achieved': fl / ms / 1e9, 'unit': 'TFLOP/s', 'avg_launch_ms': ms, 'launches': launches,
+            'shape': 'conv k3 1024->2048, B=256 T=64 (M=16384, N=2048, K=3072), random normal operands'}
+
+
 class KernelEvents(object):
     """HIP-event timing, on the launch stream, of every zs_gemm_conv launch made through ConvLayer.fwd / ConvLayer.dgrad that
     dispatches to the dominant kernel (gemm_conv_p8m16_kernel: the 256x256 ping-pong tile); the smaller layers go to the
@@ -219,6 +246,9 @@ def main():
         ke.enabled = False
         ae.use_graph = True
         log('instrumented eager steps for the roofline: %d gemm_conv launches timed' % len(ke.pairs))
+    isolated = None
+    if rank == 0 and not args.no_kernel_events:
+        isolated = isolated_kernel_rate(dev, args.dtype)
     loss = float(ae._loss.item())
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -253,6 +283,11 @@ def main():
                            'measured_on': ('instrumented eager steps after the timed region' if ae.use_graph else 'the timed steps')}
     else:
         out['roofline'] = {'bound': 'mfma', 'achieved': None, 'peak': peak, 'unit': 'TFLOP/s', 'frac': None, 'traffic': None}
+    if isolated is not None:
+        # secondary figure: the same kernel with nothing else on the GPU (in the step it shares the chip, and its power budget,
+        # with the side-stream weight gradients)
+        isolated['frac'] = isolated['achieved'] / peak
+        out['roofline']['isolated'] = isolated
     out['step_tflops'] = 180.7e6 * value / 1e12          # 180.7 MFLOP per frame for the whole step
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(seg_len, F, E, ch, nspk)
