@@ -274,6 +274,9 @@ typedef struct {
 } ZsGruFwd;
 size_t zs_gru_work_bytes(int32_t B, int32_t H);
 int zs_gru_fwd(const ZsGruFwd* p, void* stream);
+/* test / debug hook (synchronises the stream): ZS_OK unless the last persistent pass over `work` had a workgroup give up
+ * waiting for its group -- bounded spins instead of a hang; the results of that pass are then invalid */
+int zs_gru_check(const float* work, int32_t B, int32_t H, void* stream);
 typedef struct {
   int32_t dtype;
   int32_t B, T, H;

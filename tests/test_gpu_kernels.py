@@ -373,6 +373,7 @@ def _gru_case(L, layers, dtype, shape):
     gi = ctx.act('gi', B, T, 6 * H)
     gates = ctx.raw('gates', B * T * 8 * H, ctx.tdt)
     gru.fwd(X, cat, Cin, gi, gates)
+    gru.check(B)
     torch.cuda.synchronize()
     got = cat.valid()[:, :, Cin:]
     _close('gru fwd', got, out, 4 * _tol(dtype))
@@ -380,6 +381,7 @@ def _gru_case(L, layers, dtype, shape):
     dgi, dgh = ctx.act('dgi', B, T, 6 * H), ctx.act('dgh', B, T, 6 * H)
     dX = ctx.act('dX', B, T, Cin)
     gru.bwd(dcat, Cin, cat, Cin, gates, X, dgi, dgh, dX)
+    gru.check(B)
     torch.cuda.synchronize()
     tol = 6 * _tol(dtype)
     _close('gru dX', dX.valid(), xr.grad, tol)

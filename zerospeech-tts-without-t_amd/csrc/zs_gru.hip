@@ -11,6 +11,8 @@
 
 #include "zs_common.h"
 
+extern "C" size_t zs_gru_work_bytes(int32_t B, int32_t H);
+
 namespace {
 
 constexpr int NTG = 256;
@@ -740,6 +742,20 @@ extern "C" size_t zs_gru_work_bytes(int32_t B, int32_t H) {
   return steps > hx ? steps : hx;
 }
 
+// Debug / test hook: read back the error word of the persistent kernels (set when a bounded spin timed out; it lives in the
+// reserved 256-byte tail of the work buffer, which the one-launch-per-step path never touches).  Synchronises.
+extern "C" int zs_gru_check(const float* work, int32_t B, int32_t H, void* stream) {
+  ZS_REQUIRE(work && B > 0 && H > 0, "zs_gru_check: bad args");
+  unsigned v = 0;
+  if (hipMemcpyAsync(&v, reinterpret_cast<const char*>(work) + zs_gru_work_bytes(B, H) - 256, sizeof(v), hipMemcpyDeviceToHost,
+                     (hipStream_t)stream) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+    zs_set_error("zs_gru_check: copy failed");
+    return ZS_ELAUNCH;
+  }
+  if (v != 0) { zs_set_error("zs_gru_check: a persistent GRU workgroup timed out waiting for its group (results are invalid)"); return ZS_ELAUNCH; }
+  return ZS_OK;
+}
+
 extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
   ZS_REQUIRE(p && p->gi && p->whh && p->bhh && p->out && p->work, "zs_gru_fwd: null operand");
   ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_gru_fwd: bad dtype");
@@ -765,9 +781,12 @@ extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
       a.bhh = p->bhh; a.bhh_gstride = p->bhh_gstride; a.out = p->out; a.ldo = p->ldo; a.out_col = p->out_col; a.gates = p->gates;
       const size_t hx_bytes = gru_hx_bytes(B, H, es);
       a.hx = reinterpret_cast<unsigned long long*>(p->work);
-      a.err = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p->work) + hx_bytes);
+      a.err = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p->work) + zs_gru_work_bytes(B, H) - 256);   // reserved tail
       a.B = B; a.T = T; a.H = H; a.rows_pad = nrb * 16 * RB;
-      if (hipMemsetAsync(p->work, 0, hx_bytes + 16, (hipStream_t)stream) != hipSuccess) { zs_set_error("zs_gru_fwd: memset failed"); return ZS_ELAUNCH; }
+      if (hipMemsetAsync(p->work, 0, hx_bytes, (hipStream_t)stream) != hipSuccess || hipMemsetAsync(a.err, 0, 16, (hipStream_t)stream) != hipSuccess) {
+        zs_set_error("zs_gru_fwd: memset failed");
+        return ZS_ELAUNCH;
+      }
       dim3 grid(H / 32, nrb, 2);
 #define ZS_GRU_PF(TT, PP) hipLaunchKernelGGL((gru_persist_fwd_kernel<TT, PP>), grid, dim3(256), 0, (hipStream_t)stream, a)
       if (p->dtype == ZS_F32) { if (per == 1) ZS_GRU_PF(float, 1); else if (per == 2) ZS_GRU_PF(float, 2); else ZS_GRU_PF(float, 4); }
@@ -851,9 +870,12 @@ extern "C" int zs_gru_bwd(const ZsGruBwd* p, void* stream) {
       a.dgi = p->dgi; a.ldgi = p->ldgi; a.dgh = p->dgh; a.ldgh = p->ldgh;
       const size_t dx_bytes = gru_hx_bytes(B, 3 * H, es);
       a.dx = reinterpret_cast<unsigned long long*>(p->work);
-      a.err = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p->work) + dx_bytes);
+      a.err = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p->work) + zs_gru_work_bytes(B, H) - 256);   // reserved tail
       a.B = B; a.T = T; a.H = H; a.rows_pad = nrb * 16 * RB;
-      if (hipMemsetAsync(p->work, 0, dx_bytes + 16, (hipStream_t)stream) != hipSuccess) { zs_set_error("zs_gru_bwd: memset failed"); return ZS_ELAUNCH; }
+      if (hipMemsetAsync(p->work, 0, dx_bytes, (hipStream_t)stream) != hipSuccess || hipMemsetAsync(a.err, 0, 16, (hipStream_t)stream) != hipSuccess) {
+        zs_set_error("zs_gru_bwd: memset failed");
+        return ZS_ELAUNCH;
+      }
       dim3 grid(H / 32, nrb, 2);
 #define ZS_GRU_PB(TT, PP) hipLaunchKernelGGL((gru_persist_bwd_kernel<TT, PP>), grid, dim3(256), 0, (hipStream_t)stream, a)
       if (p->dtype == ZS_F32) { if (perb == 3) ZS_GRU_PB(float, 3); else if (perb == 6) ZS_GRU_PB(float, 6); else ZS_GRU_PB(float, 12); }

@@ -353,6 +353,10 @@ class GruLayer(object):
                gates=L.ptr(gates) if gates is not None else None, work=L.ptr(work), work_bytes=work.numel() * 4,
                whh_interleaved=int(self.fast))
 
+    def check(self, B):
+        """Test hook: raise if the last persistent pass over this layer's work buffer timed out (synchronises)."""
+        L.check(L.lib().zs_gru_check(L.ptr(self._work(B)), B, self.H, self.ctx.stream), 'zs_gru_check')
+
     def bwd(self, dout, dout_col, out, out_col, gates, X, dgi, dgh, dX, add_src=None):
         """BPTT + parameter gradients + input gradient dX (= dgi W_ih, + add_src)."""
         c, H = self.ctx, self.H
