@@ -368,10 +368,10 @@ __device__ __forceinline__ void store_granule(unsigned long long* g, unsigned ta
 }
 template <typename T> struct Pair;
 template <> struct Pair<bf16_t> {
-  static __device__ __forceinline__ void ld(const bf16_t* p, float& a, float& b) {
-    const unsigned w = *reinterpret_cast<const unsigned*>(p);
-    a = __uint_as_float(w << 16); b = __uint_as_float(w & 0xffff0000u);
-  }
+  typedef unsigned raw_t;            // two bf16 as loaded: converting at the load site would park the wave on the HBM latency
+  static __device__ __forceinline__ raw_t ld_raw(const bf16_t* p) { return *reinterpret_cast<const unsigned*>(p); }
+  static __device__ __forceinline__ void cvt(raw_t w, float& a, float& b) { a = __uint_as_float(w << 16); b = __uint_as_float(w & 0xffff0000u); }
+  static __device__ __forceinline__ void ld(const bf16_t* p, float& a, float& b) { cvt(ld_raw(p), a, b); }
   static __device__ __forceinline__ unsigned pack(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
   static __device__ __forceinline__ void st(bf16_t* p, float a, float b) { *reinterpret_cast<unsigned*>(p) = pack(a, b); }
   // the pair (unit j, j+1) of a row is ONE granule
@@ -380,7 +380,10 @@ template <> struct Pair<bf16_t> {
   }
 };
 template <> struct Pair<float> {
-  static __device__ __forceinline__ void ld(const float* p, float& a, float& b) { const float2 v = *reinterpret_cast<const float2*>(p); a = v.x; b = v.y; }
+  typedef float2 raw_t;
+  static __device__ __forceinline__ raw_t ld_raw(const float* p) { return *reinterpret_cast<const float2*>(p); }
+  static __device__ __forceinline__ void cvt(raw_t v, float& a, float& b) { a = v.x; b = v.y; }
+  static __device__ __forceinline__ void ld(const float* p, float& a, float& b) { cvt(ld_raw(p), a, b); }
   static __device__ __forceinline__ void st(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
   static __device__ __forceinline__ void publish(unsigned long long* row, int j, unsigned tag, float a, float b) {
     store_granule(row + j, tag, __float_as_uint(a));
@@ -434,15 +437,12 @@ __global__ __launch_bounds__(256) void gru_persist_fwd_kernel(const GruPersistAr
   for (int s = 0; s < T_; ++s) {
     const int t = d == 0 ? s : T_ - 1 - s;
     // gate inputs of this step do not depend on other workgroups: issue them before the sweep
-    float gi_r[2][2], gi_z[2][2], gi_n[2][2];
+    typename Pair<T>::raw_t q_r[2], q_z[2], q_n[2];
 #pragma unroll
     for (int pz = 0; pz < 2; ++pz) {
-      const int b = m0 + e_row + 16 * pz;
-      gi_r[pz][0] = gi_r[pz][1] = gi_z[pz][0] = gi_z[pz][1] = gi_n[pz][0] = gi_n[pz][1] = 0.f;
-      if (b < a.B) {
-        const T* gi = (const T*)a.gi + ((int64_t)b * T_ + t) * a.ldgi + (int64_t)d * 3 * H + j;
-        Pair<T>::ld(gi, gi_r[pz][0], gi_r[pz][1]); Pair<T>::ld(gi + H, gi_z[pz][0], gi_z[pz][1]); Pair<T>::ld(gi + 2 * H, gi_n[pz][0], gi_n[pz][1]);
-      }
+      const int b = min(m0 + e_row + 16 * pz, a.B - 1);      // rows past B: any valid address, the values are not used
+      const T* gi = (const T*)a.gi + ((int64_t)b * T_ + t) * a.ldgi + (int64_t)d * 3 * H + j;
+      q_r[pz] = Pair<T>::ld_raw(gi); q_z[pz] = Pair<T>::ld_raw(gi + H); q_n[pz] = Pair<T>::ld_raw(gi + 2 * H);
     }
     f32x4_t acc[RB][6];
 #pragma unroll
@@ -509,14 +509,15 @@ __global__ __launch_bounds__(256) void gru_persist_fwd_kernel(const GruPersistAr
       const int rr = e_row + 16 * pz;
       const int b = m0 + rr;
       if (b < a.B) {
-        float hv[2], rg[2], zg[2], ng[2], hn[2];
+        float hv[2], rg[2], zg[2], ng[2], hn[2], gi_r[2], gi_z[2], gi_n[2];
+        Pair<T>::cvt(q_r[pz], gi_r[0], gi_r[1]); Pair<T>::cvt(q_z[pz], gi_z[0], gi_z[1]); Pair<T>::cvt(q_n[pz], gi_n[0], gi_n[1]);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const float ghr = total(hh, rr, cc + e), ghz = total(2 + hh, rr, cc + e), ghn = total(4 + hh, rr, cc + e);
-          rg[e] = 1.f / (1.f + expf(-(gi_r[pz][e] + (ghr + (e ? b_r1 : b_r0)))));
-          zg[e] = 1.f / (1.f + expf(-(gi_z[pz][e] + (ghz + (e ? b_z1 : b_z0)))));
+          rg[e] = 1.f / (1.f + expf(-(gi_r[e] + (ghr + (e ? b_r1 : b_r0)))));
+          zg[e] = 1.f / (1.f + expf(-(gi_z[e] + (ghz + (e ? b_z1 : b_z0)))));
           hn[e] = ghn + (e ? b_n1 : b_n0);
-          ng[e] = tanhf(gi_n[pz][e] + rg[e] * hn[e]);
+          ng[e] = tanhf(gi_n[e] + rg[e] * hn[e]);
           hv[e] = (1.f - zg[e]) * ng[e] + zg[e] * hp[pz][e];
           hp[pz][e] = hv[e];
         }
@@ -589,23 +590,16 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_kernel(const GruPersistBw
   for (int s = 0; s < T_; ++s) {
     const int t = d == 0 ? T_ - 1 - s : s;              // reverse of the forward order
     // operands of this step's gate math that no other workgroup writes in this launch: issue before the sweep
-    float w_r[2][2], w_z[2][2], w_n[2][2], w_hn[2][2], w_do[2][2], w_hp[2][2];
+    typename Pair<T>::raw_t q_r[2], q_z[2], q_n[2], q_hn[2], q_do[2], q_hp[2];
 #pragma unroll
     for (int pz = 0; pz < 2; ++pz) {
-      const int b = m0 + e_row + 16 * pz;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) w_r[pz][e] = w_z[pz][e] = w_n[pz][e] = w_hn[pz][e] = w_do[pz][e] = w_hp[pz][e] = 0.f;
-      if (b < a.B) {
-        const int64_t row = (int64_t)b * T_ + t;
-        const T* gs = (const T*)a.gates + (row * 2 + d) * 4 * H + j;
-        Pair<T>::ld(gs, w_r[pz][0], w_r[pz][1]); Pair<T>::ld(gs + H, w_z[pz][0], w_z[pz][1]);
-        Pair<T>::ld(gs + 2 * H, w_n[pz][0], w_n[pz][1]); Pair<T>::ld(gs + 3 * H, w_hn[pz][0], w_hn[pz][1]);
-        Pair<T>::ld((const T*)a.dout + row * a.ldd + a.dout_col + d * H + j, w_do[pz][0], w_do[pz][1]);
-        if (s < T_ - 1) {
-          const int tp = d == 0 ? t - 1 : t + 1;
-          Pair<T>::ld((const T*)a.out + ((int64_t)b * T_ + tp) * a.ldo + a.out_col + d * H + j, w_hp[pz][0], w_hp[pz][1]);
-        }
-      }
+      const int b = min(m0 + e_row + 16 * pz, a.B - 1);      // rows past B: any valid address, the values are not used
+      const int64_t row = (int64_t)b * T_ + t;
+      const T* gs = (const T*)a.gates + (row * 2 + d) * 4 * H + j;
+      q_r[pz] = Pair<T>::ld_raw(gs); q_z[pz] = Pair<T>::ld_raw(gs + H); q_n[pz] = Pair<T>::ld_raw(gs + 2 * H); q_hn[pz] = Pair<T>::ld_raw(gs + 3 * H);
+      q_do[pz] = Pair<T>::ld_raw((const T*)a.dout + row * a.ldd + a.dout_col + d * H + j);
+      const int tp = s < T_ - 1 ? (d == 0 ? t - 1 : t + 1) : t;       // last BPTT step: h_prev = 0 (handled below)
+      q_hp[pz] = Pair<T>::ld_raw((const T*)a.out + ((int64_t)b * T_ + tp) * a.ldo + a.out_col + d * H + j);
     }
     f32x4_t acc[RB][2];
 #pragma unroll
@@ -671,17 +665,20 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_kernel(const GruPersistBw
       const int rr = e_row + 16 * pz;
       const int b = m0 + rr;
       if (b < a.B) {
-        float dr_pre[2], dz_pre[2], dn_pre[2], dnr[2];
+        float dr_pre[2], dz_pre[2], dn_pre[2], dnr[2], w_r[2], w_z[2], w_n[2], w_hn[2], w_do[2], w_hp[2];
+        Pair<T>::cvt(q_r[pz], w_r[0], w_r[1]); Pair<T>::cvt(q_z[pz], w_z[0], w_z[1]); Pair<T>::cvt(q_n[pz], w_n[0], w_n[1]);
+        Pair<T>::cvt(q_hn[pz], w_hn[0], w_hn[1]); Pair<T>::cvt(q_do[pz], w_do[0], w_do[1]); Pair<T>::cvt(q_hp[pz], w_hp[0], w_hp[1]);
+        if (s == T_ - 1) w_hp[0] = w_hp[1] = 0.f;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          float dh = w_do[pz][e] + dhd[pz][e];
+          float dh = w_do[e] + dhd[pz][e];
           if (s > 0) dh += total(hh, rr, cc + e);
-          const float r_ = w_r[pz][e], z_ = w_z[pz][e], n_ = w_n[pz][e];
+          const float r_ = w_r[e], z_ = w_z[e], n_ = w_n[e];
           const float dn = dh * (1.f - z_);
-          const float dz = dh * (w_hp[pz][e] - n_);
+          const float dz = dh * (w_hp[e] - n_);
           dhd[pz][e] = dh * z_;
           dn_pre[e] = dn * (1.f - n_ * n_);
-          dr_pre[e] = dn_pre[e] * w_hn[pz][e] * r_ * (1.f - r_);
+          dr_pre[e] = dn_pre[e] * w_hn[e] * r_ * (1.f - r_);
           dz_pre[e] = dz * z_ * (1.f - z_);
           dnr[e] = dn_pre[e] * r_;
         }
