@@ -265,7 +265,7 @@ def main():
         'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': 'train_ae english hps seg_len=128 enc_size=1024 emb_size=1024 n_speakers=102 F=513, batch=%d/GPU, '
                                'dropout+Gumbel on, fwd+bwd+clip+Adam' % B, 'global_batch': B * world, 'parallelism': 'dp%d' % world},
-        'final_loss': loss, 'host_input': bool(args.host_input), 'host_enqueue_ms_per_step': 1e3 * t_host / args.steps, 'hipgraph': bool(ae.use_graph),
+        'final_loss': loss, 'host_input': bool(args.host_input), 'host_enqueue_ms_per_step': 1e3 * t_host / args.steps, 'hipgraph': bool(ae.use_graph and (world == 1 or os.environ.get('ZS_GRAPH_MULTI', '0') == '1')),
     }
     peak = 2500.0 if args.dtype == 'bf16' else 157.3
     traffic = None

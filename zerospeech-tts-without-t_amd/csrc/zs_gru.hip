@@ -551,38 +551,36 @@ struct GruPersistBwdArgs {
   int B, T, H, rows_pad;
 };
 
+// Tiling: 64 hidden units x 16 rows per workgroup (forward: 32 x 32): the BPTT sweep reads all 3H columns of its rows, so fewer
+// rows per workgroup halve the granule traffic (31 MB per time step with 32 rows); W_hh^T slice = 64 x 3H = 192 VGPRs per lane.
+constexpr int BNT = 4;             // 16-column MFMA tiles per workgroup (64 units)
 template <typename T, int PERB>    // PERB = k-steps per wave: 3H = 4 * PERB * KSTEP
 __global__ __launch_bounds__(256) void gru_persist_bwd_kernel(const GruPersistBwdArgs a) {
   constexpr int KSTEP = Frag16<T>::KSTEP;
   constexpr int EPL = 16 / (int)sizeof(T);
   constexpr int GPE = 4 / (int)sizeof(T);
-  __shared__ float part[4][RB][2][4][64];
+  __shared__ float part[4][BNT][4][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, r = lane & 15;
   const int d = blockIdx.z, H = a.H, T_ = a.T;
-  const int m0 = blockIdx.y * 16 * RB;
+  const int m0 = blockIdx.y * 16;
   const int gpr = 3 * H / GPE;
   const int64_t par_stride = (int64_t)a.rows_pad * gpr;
   unsigned long long* dx_d = a.dx + (int64_t)d * 2 * par_stride;
 
-  uint4 fb[PERB][2];
+  uint4 fb[PERB][BNT];
   {
-    const T* Wrow = (const T*)a.whh_t + (int64_t)d * a.w_gstride + (int64_t)(blockIdx.x * 32 + r) * a.ldw + q * EPL;
+    const T* Wrow = (const T*)a.whh_t + (int64_t)d * a.w_gstride + (int64_t)(blockIdx.x * 16 * BNT + r) * a.ldw + q * EPL;
 #pragma unroll
     for (int u = 0; u < PERB; ++u)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) fb[u][c] = *reinterpret_cast<const uint4*>(Wrow + (int64_t)(16 * c) * a.ldw + (wave * PERB + u) * KSTEP);
+      for (int c = 0; c < BNT; ++c) fb[u][c] = *reinterpret_cast<const uint4*>(Wrow + (int64_t)(16 * c) * a.ldw + (wave * PERB + u) * KSTEP);
   }
-  const unsigned long long* Ag[RB];
-  bool rvalid[RB];
-#pragma unroll
-  for (int rb = 0; rb < RB; ++rb) {
-    const int row = m0 + 16 * rb + r;
-    rvalid[rb] = row < a.B;
-    Ag[rb] = dx_d + (int64_t)row * gpr + (q * EPL + wave * PERB * KSTEP) / GPE;
-  }
-  const int eu2 = tid & 15, e_row = tid >> 4;
-  const int j = blockIdx.x * 32 + 2 * eu2;
+  const bool rvalid = (m0 + r) < a.B;
+  const unsigned long long* Ag = dx_d + (int64_t)(m0 + r) * gpr + (q * EPL + wave * PERB * KSTEP) / GPE;
+  // gate-math ownership: unit pair (2*eu2, 2*eu2+1) of the 64 units, rows e_row + 8*pz
+  const int eu2 = tid & 31, e_row = tid >> 5;
+  const int j = blockIdx.x * 16 * BNT + 2 * eu2;
   const int hh = (2 * eu2) >> 4, cc = (2 * eu2) & 15;
   float dhd[2][2] = {{0.f, 0.f}, {0.f, 0.f}};          // direct carry dh * z of the previous BPTT step
   bool dead = false;
@@ -593,7 +591,7 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_kernel(const GruPersistBw
     typename Pair<T>::raw_t q_r[2], q_z[2], q_n[2], q_hn[2], q_do[2], q_hp[2];
 #pragma unroll
     for (int pz = 0; pz < 2; ++pz) {
-      const int b = min(m0 + e_row + 16 * pz, a.B - 1);      // rows past B: any valid address, the values are not used
+      const int b = min(m0 + e_row + 8 * pz, a.B - 1);       // rows past B: any valid address, the values are not used
       const int64_t row = (int64_t)b * T_ + t;
       const T* gs = (const T*)a.gates + (row * 2 + d) * 4 * H + j;
       q_r[pz] = Pair<T>::ld_raw(gs); q_z[pz] = Pair<T>::ld_raw(gs + H); q_n[pz] = Pair<T>::ld_raw(gs + 2 * H); q_hn[pz] = Pair<T>::ld_raw(gs + 3 * H);
@@ -601,35 +599,29 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_kernel(const GruPersistBw
       const int tp = s < T_ - 1 ? (d == 0 ? t - 1 : t + 1) : t;       // last BPTT step: h_prev = 0 (handled below)
       q_hp[pz] = Pair<T>::ld_raw((const T*)a.out + ((int64_t)b * T_ + tp) * a.ldo + a.out_col + d * H + j);
     }
-    f32x4_t acc[RB][2];
+    f32x4_t acc[BNT];
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) acc[rb][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < BNT; ++c) acc[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
       const int64_t poff = (int64_t)((s - 1) & 1) * par_stride;
-      gu32x4_t g0[PERB][RB], g1[PERB][RB];
+      gu32x4_t g0[PERB], g1[PERB];
       unsigned spins = 0;
       for (;;) {
 #pragma unroll
-        for (int u = 0; u < PERB; ++u)
-#pragma unroll
-          for (int rb = 0; rb < RB; ++rb) {
-            const unsigned long long* gp = Ag[rb] + poff + (u * KSTEP) / GPE;
-            load16_sc1_issue(g0[u][rb], gp);
-            load16_sc1_issue(g1[u][rb], gp + 2);
-          }
+        for (int u = 0; u < PERB; ++u) {
+          const unsigned long long* gp = Ag + poff + (u * KSTEP) / GPE;
+          load16_sc1_issue(g0[u], gp);
+          load16_sc1_issue(g1[u], gp + 2);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         bool ok = true;
 #pragma unroll
-        for (int u = 0; u < PERB; ++u)
-#pragma unroll
-          for (int rb = 0; rb < RB; ++rb) {
-            asm volatile("" : "+v"(g0[u][rb]), "+v"(g1[u][rb]));
-            const bool m = (g0[u][rb].y == (unsigned)s) & (g0[u][rb].w == (unsigned)s) & (g1[u][rb].y == (unsigned)s) & (g1[u][rb].w == (unsigned)s);
-            ok &= (m | !rvalid[rb]);
-          }
+        for (int u = 0; u < PERB; ++u) {
+          asm volatile("" : "+v"(g0[u]), "+v"(g1[u]));
+          const bool m = (g0[u].y == (unsigned)s) & (g0[u].w == (unsigned)s) & (g1[u].y == (unsigned)s) & (g1[u].w == (unsigned)s);
+          ok &= (m | !rvalid);
+        }
         if (__all(ok) || dead) break;
         __builtin_amdgcn_s_sleep(1);
         if (++spins > GRU_SPIN_LIMIT) {
@@ -639,30 +631,26 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_kernel(const GruPersistBw
         }
       }
 #pragma unroll
-      for (int u = 0; u < PERB; ++u)
+      for (int u = 0; u < PERB; ++u) {
+        uint4 fa = make_uint4(g0[u].x, g0[u].z, g1[u].x, g1[u].z);
+        if (!rvalid) fa = make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-          uint4 fa = make_uint4(g0[u][rb].x, g0[u][rb].z, g1[u][rb].x, g1[u][rb].z);
-          if (!rvalid[rb]) fa = make_uint4(0, 0, 0, 0);
-#pragma unroll
-          for (int c = 0; c < 2; ++c) Frag16<T>::mma(fa, fb[u][c], acc[rb][c]);
-        }
+        for (int c = 0; c < BNT; ++c) Frag16<T>::mma(fa, fb[u][c], acc[c]);
+      }
     }
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
+    for (int c = 0; c < BNT; ++c)
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) part[wave][rb][c][i][lane] = acc[rb][c][i];
+      for (int i = 0; i < 4; ++i) part[wave][c][i][lane] = acc[c][i];
     __syncthreads();
-    auto total = [&](int c, int rr, int col) -> float {
-      const int rb = rr >> 4, l = ((rr & 15) >> 2) * 16 + col, i = rr & 3;
-      return (part[0][rb][c][i][l] + part[1][rb][c][i][l]) + (part[2][rb][c][i][l] + part[3][rb][c][i][l]);
+    auto total = [&](int c, int rr, int col) -> float {      // row rr (0..15), column col of tile c
+      const int l = (rr >> 2) * 16 + col, i = rr & 3;
+      return (part[0][c][i][l] + part[1][c][i][l]) + (part[2][c][i][l] + part[3][c][i][l]);
     };
     unsigned long long* dx_w = dx_d + (int64_t)(s & 1) * par_stride;
 #pragma unroll
     for (int pz = 0; pz < 2; ++pz) {
-      const int rr = e_row + 16 * pz;
+      const int rr = e_row + 8 * pz;
       const int b = m0 + rr;
       if (b < a.B) {
         float dr_pre[2], dz_pre[2], dn_pre[2], dnr[2], w_r[2], w_z[2], w_n[2], w_hn[2], w_do[2], w_hp[2];
@@ -855,10 +843,10 @@ extern "C" int zs_gru_bwd(const ZsGruBwd* p, void* stream) {
   const char* dghb = (const char*)p->dgh;
   const bool fast = (H % 32 == 0);
   if (fast && gru_persist_enabled() && T > 1) {
-    const int nrb = (B + 16 * RB - 1) / (16 * RB);
+    const int nrb = (B + 15) / 16;                         // 16 rows x 64 units per workgroup
     const int kstep = p->dtype == ZS_F32 ? 16 : 32;
-    const int perb = ((3 * H) % (4 * kstep) == 0) ? (3 * H) / (4 * kstep) : 0;
-    const int64_t nwg = (int64_t)(H / 32) * nrb * 2;
+    const int perb = ((3 * H) % (4 * kstep) == 0 && H % (16 * BNT) == 0) ? (3 * H) / (4 * kstep) : 0;
+    const int64_t nwg = (int64_t)(H / (16 * BNT)) * nrb * 2;
     if ((perb == 3 || perb == 6 || perb == 12) && nwg <= gru_resident_limit()) {
       GruPersistBwdArgs a;
       memset(&a, 0, sizeof(a));
@@ -868,12 +856,12 @@ extern "C" int zs_gru_bwd(const ZsGruBwd* p, void* stream) {
       const size_t dx_bytes = gru_hx_bytes(B, 3 * H, es);
       a.dx = reinterpret_cast<unsigned long long*>(p->work);
       a.err = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p->work) + zs_gru_work_bytes(B, H) - 256);   // reserved tail
-      a.B = B; a.T = T; a.H = H; a.rows_pad = nrb * 16 * RB;
+      a.B = B; a.T = T; a.H = H; a.rows_pad = nrb * 16;
       if (hipMemsetAsync(p->work, 0, dx_bytes, (hipStream_t)stream) != hipSuccess || hipMemsetAsync(a.err, 0, 16, (hipStream_t)stream) != hipSuccess) {
         zs_set_error("zs_gru_bwd: memset failed");
         return ZS_ELAUNCH;
       }
-      dim3 grid(H / 32, nrb, 2);
+      dim3 grid(H / (16 * BNT), nrb, 2);
 #define ZS_GRU_PB(TT, PP) hipLaunchKernelGGL((gru_persist_bwd_kernel<TT, PP>), grid, dim3(256), 0, (hipStream_t)stream, a)
       if (p->dtype == ZS_F32) { if (perb == 3) ZS_GRU_PB(float, 3); else if (perb == 6) ZS_GRU_PB(float, 6); else ZS_GRU_PB(float, 12); }
       else { if (perb == 3) ZS_GRU_PB(bf16_t, 3); else if (perb == 6) ZS_GRU_PB(bf16_t, 6); else ZS_GRU_PB(bf16_t, 12); }
