@@ -7,7 +7,7 @@ Every arithmetic step is a libzs_amd.so kernel; torch only owns the memory.
 import torch
 
 from . import _lib as L
-from .layers import Act, ConvLayer, GruLayer, rup
+from .layers import Act, ConvLayer, GruLayer, fork_side, join_side, rup
 
 LRELU = L.ZS_ACT_LRELU
 EPS_IN = 1e-5
@@ -74,8 +74,16 @@ class EncoderEngine(object):
                dst_f32=0, col_off=0, rows=B * T, cols=F, fill_cols=xin.ld, act=L.ZS_ACT_NONE)
         L.call('zs_cast_rows', 'ZsCastRows', st, dtype=c.dt, src=L.ptr(x), ld_src=F, src_f32=1, dst=cat.ptr(), ld_dst=cat.ld,
                dst_f32=0, col_off=7 * c1, rows=B * T, cols=F, fill_cols=cat.ld - 7 * c1, act=LRELU, slope=ns)   # :445-446
-        for i, l in enumerate(self.conv1s):                                                                   # :441-444
-            l.fwd(xin, out=cat.sub(i * c1, c1), act=LRELU, slope=ns)
+        if c.overlap_wgrad and B * T >= 4096:
+            # the seven bank convs are independent and each fills half the chip at most (N = 128): run them side by side
+            sts = fork_side(c.device)
+            for i, l in enumerate(self.conv1s):                                                               # :441-444
+                with torch.cuda.stream(sts[i % len(sts)]):
+                    l.fwd(xin, out=cat.sub(i * c1, c1), act=LRELU, slope=ns)
+            join_side(c.device)
+        else:
+            for i, l in enumerate(self.conv1s):
+                l.fwd(xin, out=cat.sub(i * c1, c1), act=LRELU, slope=ns)
         y2 = c.act('e_y2' + tag, B, T, c2)
         self.conv2.fwd(cat, out=y2, act=LRELU, slope=ns)                                                      # :447
         a = c.act('e_a0' + tag, B, T, c2)

@@ -69,6 +69,18 @@ def side_events(device):
     return evs
 
 
+def fork_side(device):
+    """Make every side stream wait for what is enqueued on the current stream so far; returns the side streams.  Used to run
+    independent small launches of the main chain (the encoder's 7-conv bank) side by side; close with join_side()."""
+    sd = side_stream(device)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    for st in sd['streams']:
+        st.wait_event(ev)
+    sd['used'] = True
+    return sd['streams']
+
+
 def join_side(device):
     """Make the current stream wait for everything enqueued on the side streams."""
     sd = side_stream(device)
