@@ -4,6 +4,7 @@ EncoderEngine  <->  Encoder.forward          (reference model/model.py:440-489) 
 DecoderEngine  <->  Decoder.forward          (reference model/model.py:344-365) and its autograd backward
 Every arithmetic step is a libzs_amd.so kernel; torch only owns the memory.
 """
+import os
 import torch
 
 from . import _lib as L
@@ -385,8 +386,11 @@ class DecoderEngine(object):
             dn = c.act('d_dxC%d' % i + tag, B, Ti, ch)
             self._combine(gp1, Ti, 1, 1, dn, emb_i=i, res_mode=L.ZS_RES_UPSAMPLE2, res=dx)   # x+emb (:319) and upsample(x) (:329)
             dx = dn
-        for k in range(5):                             # nn.Embedding backward, fixed sample order
-            L.call('zs_emb_scatter', 'ZsEmbScatter', c.stream, emb_sum=L.ptr(self._embsum, k * B * ch), emb_ld=ch,
+        # nn.Embedding backward, fixed sample order.  Only the optimizer needs these: off the main chain, side by side
+        sts = fork_side(c.device) if c.overlap_wgrad else None
+        for k in range(5):
+            st_k = sts[k % len(sts)].cuda_stream if sts is not None else c.stream
+            L.call('zs_emb_scatter', 'ZsEmbScatter', st_k, emb_sum=L.ptr(self._embsum, k * B * ch), emb_ld=ch,
                    idx=L.ptr(tp['cidx']), B=B, demb=L.ptr(self.gemb[k]), demb_ld=ch, n_rows=self.n_spk, C=ch, accumulate=0)
         bits = tp['bits']
         self.input_emb.wgrad(dx, bits)
