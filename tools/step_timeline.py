@@ -12,7 +12,7 @@ for r in rows:
 rows.sort(key=lambda r: r['s'])
 # a step ends with the encoder's Adam launch (the decoder's runs earlier on the optimizer stream): every second adam_kernel
 ad = [i for i, r in enumerate(rows) if r['n'].startswith('adam_kernel')]
-k = int(sys.argv[2]) if len(sys.argv) > 2 else len(ad) // 2 - 8
+k = int(sys.argv[2]) if len(sys.argv) > 2 else max(1, len(ad) // 4)      # default: a step inside the timed (graph replay) region of bench.py
 a, b = rows[ad[2 * k + 1]]['e'], rows[ad[2 * k + 3]]['e']
 sel = [r for r in rows if r['s'] >= a and r['e'] <= b]
 
