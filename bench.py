@@ -199,11 +199,24 @@ def main():
     x = (torch.rand(B, seg_len, F, generator=g) * (1 - 1e-8) + 1e-8).to(dev)
     c = torch.randint(0, nspk, (B,), generator=g).to(dev)
 
-    x_host = x.cpu().pin_memory() if args.host_input else None
+    prefetch = None
+    if args.host_input:
+        # the batch comes from host memory every step through the DevicePrefetcher (pinned staging, copy stream, double buffer)
+        from zs_amd.dataloader import DevicePrefetcher
+
+        class _HostBatches(object):
+            def __init__(self, c_host, x_host):
+                self.c, self.x = c_host, x_host
+
+            def __next__(self):
+                return self.c, self.x
+
+        prefetch = DevicePrefetcher(_HostBatches(c.cpu().pin_memory(), x.cpu().pin_memory()), dev)
 
     def one_step():
-        if x_host is not None:
-            x.copy_(x_host, non_blocking=True)        # 67.2 MB H2D per step at B=256
+        if prefetch is not None:
+            cb, xb = next(prefetch)                   # 67.2 MB H2D per step at B=256, issued one step ahead
+            return ae.step(xb, cb)
         return ae.step(x, c)
 
     ke = KernelEvents()

@@ -36,6 +36,51 @@ class DataLoader(object):
         return self._fetch(self.batch_size)
 
 
+class DevicePrefetcher(object):
+    """Keeps the GPU fed from a host DataLoader (rows a1/a2 of SURVEY section 8: the reference builds the batch on the host
+    and copies 67 MB per step synchronously, trainer.py:238-244): the NEXT batch is staged in pinned memory and copied on a
+    separate HIP stream while the current step runs; `next()` returns device tensors `(c int64[B], x fp32[B, seg_len, F])`
+    that stay valid until the call after next (double buffering)."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, torch.device(device)
+        self.stream = torch.cuda.Stream(self.device)
+        self.slots = [None, None]            # (pinned c, pinned x, dev c, dev x, event)
+        self.turn = 0
+        self._issue(0)
+
+    def _issue(self, i):
+        c, x = next(self.loader)[:2]
+        x = x.float().contiguous()
+        c = c.long().contiguous()
+        sl = self.slots[i]
+        if sl is None or sl[1].shape != x.shape or sl[0].shape != c.shape:
+            sl = [torch.empty(c.shape, dtype=torch.int64).pin_memory(), torch.empty(x.shape, dtype=torch.float32).pin_memory(),
+                  torch.empty(c.shape, dtype=torch.int64, device=self.device), torch.empty(x.shape, dtype=torch.float32, device=self.device),
+                  torch.cuda.Event()]
+            self.slots[i] = sl
+        src_c, src_x = (c, x) if (c.is_pinned() and x.is_pinned()) else (sl[0], sl[1])
+        if src_x is sl[1]:
+            sl[0].copy_(c); sl[1].copy_(x)          # pageable batch: stage it (a 67 MB host memcpy per step at B=256)
+        # the device buffers of this slot were last read by the step issued two calls ago on the consumer's stream
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.stream):
+            sl[2].copy_(src_c, non_blocking=True)
+            sl[3].copy_(src_x, non_blocking=True)
+            sl[4].record(self.stream)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        i = self.turn
+        sl = self.slots[i]
+        torch.cuda.current_stream(self.device).wait_event(sl[4])
+        self.turn = 1 - i
+        self._issue(self.turn)               # start the copy of the following batch now: it runs under this step
+        return sl[2], sl[3]
+
+
 class Dataset(torch.utils.data.Dataset):
     """HDF5-backed segments, dataloader.py:56-78 (layout `{dset}/{speaker}/{utt}/lin|mel`)."""
 

@@ -344,6 +344,7 @@ class Trainer(object):
     def __init__(self, hps, data_loader, g_mode, enc_mode, log_dir='./log/', dtype=None, device=None):
         self.hps = hps
         self.data_loader = data_loader
+        self._prefetch = None
         self.model_kept = []
         self.max_keep = hps.max_to_keep
         self.logger = Logger(log_dir)
@@ -481,10 +482,10 @@ class Trainer(object):
 
     # ---- the loop (trainer.py:316-347) -----------------------------------------------------------
     def _batch(self):
-        data = next(self.data_loader)
-        c = data[0].to(self.device, non_blocking=True)
-        x = data[1].to(self.device, non_blocking=True).float().contiguous()              # [B, seg_len, 513]
-        return c, x
+        if self._prefetch is None:
+            from .dataloader import DevicePrefetcher
+            self._prefetch = DevicePrefetcher(self.data_loader, self.device)     # next batch copied under the current step
+        return next(self._prefetch)
 
     def train(self, model_path, flag='train', mode='train', target_guided=False):
         hps = self.hps
