@@ -182,9 +182,13 @@ def main():
     import torch.distributed as dist
 
     torch.set_num_threads(cpu_share())
-    rank, world, local = parallel.init_from_env('nccl')
+    # ZS_DIST_BACKEND / ZS_FORCE_DEVICE: rehearsal of the multi-rank path on a one-GPU box (gloo, every rank on cuda:0)
+    force_dev = os.environ.get('ZS_FORCE_DEVICE')
+    if force_dev is not None:
+        torch.cuda.set_device(int(force_dev))
+    rank, world, local = parallel.init_from_env(os.environ.get('ZS_DIST_BACKEND', 'nccl'))
     assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
-    dev = torch.device('cuda', local)
+    dev = torch.device('cuda', int(force_dev) if force_dev is not None else local)
     torch.cuda.set_device(dev)
     seg_len, F, E, ch, nspk, B = 128, 513, 1024, 1024, 102, args.batch
     torch.manual_seed(1234 + rank)
@@ -268,6 +272,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank != 0:
+        dist.barrier()                                # rank 0 is still measuring / printing: leave together
+        dist.destroy_process_group()
         return
     frames = float(B) * seg_len * args.steps * world
     value = frames / dt
@@ -304,7 +310,10 @@ def main():
     out['step_tflops'] = 180.7e6 * value / 1e12          # 180.7 MFLOP per frame for the whole step
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(seg_len, F, E, ch, nspk)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -22,7 +22,7 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        if backend == 'nccl':
+        if backend == 'nccl' and os.environ.get('ZS_FORCE_DEVICE') is None:
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
