@@ -454,6 +454,30 @@ def test_pack_weight_known_answer(zs):
     assert wd.sum() == w.sum()
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_pack_weight_batch_equals_single_calls(zs, dtype):
+    """zs_pack_weight_batch (one launch per 32 jobs) writes exactly what the per-job zs_pack_weight calls write; 40 jobs
+    of different shapes, kernel sizes and split2 flags span two launches."""
+    L, layers = zs
+    ctx = _ctx(layers, dtype)
+    g = torch.Generator().manual_seed(9)
+    specs = [(8 + 4 * (i % 5), 16 + 8 * (i % 3), 1 + (i % 4), bool(i % 2)) for i in range(20)]
+    convs_a, convs_b = [], []
+    for (co, ci, k, sp) in specs:
+        w = torch.randn(co, ci, k, generator=g)
+        convs_a.append(layers.ConvLayer(ctx, w.to(ctx.device), None, torch.zeros_like(w).to(ctx.device), None, split2=sp))
+        convs_b.append(layers.ConvLayer(ctx, w.to(ctx.device), None, torch.zeros_like(w).to(ctx.device), None, split2=sp))
+    for l in convs_a:
+        l.pack()                                          # 40 separate launches
+    with L.pack_batch(ctx.stream):
+        for l in convs_b:
+            l.pack()                                      # 2 launches
+    torch.cuda.synchronize()
+    for la, lb in zip(convs_a, convs_b):
+        assert torch.equal(la.wf, lb.wf) and torch.equal(la.wd, lb.wd)
+        assert float(la.wf.float().abs().sum()) > 0
+
+
 def test_errors_are_loud(zs):
     L, layers = zs
     ctx = _ctx(layers, 'fp32')
