@@ -242,20 +242,25 @@ def encode_batch(specs, trainer, seg_len, decode_speakers=None, noise_fn=None, m
     for it in items:
         by_len.setdefault(it[3] - it[2], []).append(it)
     enc_out, dec_out = {}, {}
+    pending = []                                          # (chunk, device encodings, device spectrograms): one host sync at the end
     for Tf, group in sorted(by_len.items()):
         for lo in range(0, len(group), max_batch):
             chunk = group[lo:lo + max_batch]
-            x = torch.from_numpy(np.stack([padded[u][a:b] for (u, _, a, b, _) in chunk])).to(dev)        # [n, Tf, 513]
+            x = torch.from_numpy(np.stack([padded[u][a:b] for (u, _, a, b, _) in chunk])).to(dev, non_blocking=True)   # [n, Tf, 513]
             G = noise_fn(len(chunk), ((((Tf + 1) // 2 + 1) // 2) + 1) // 2, enc.enc_size) if noise_fn is not None else None
             act, _ = enc(x.permute(0, 2, 1), G=G)
+            xd = None
             if decode_speakers is not None:
-                c = torch.tensor([decode_speakers[u] for (u, _, _, _, _) in chunk], dtype=torch.int64, device=dev)
-                xd = dec(act, c).permute(0, 2, 1).cpu().numpy()
-            e = act.permute(0, 2, 1).cpu().numpy()
-            for i, (u, k, _, _, trunc) in enumerate(chunk):
-                enc_out[(u, k)] = e[i][:trunc] if trunc is not None else e[i]
-                if decode_speakers is not None:
-                    dec_out[(u, k)] = xd[i]
+                c = torch.tensor([decode_speakers[u] for (u, _, _, _, _) in chunk], dtype=torch.int64).to(dev, non_blocking=True)
+                xd = dec(act, c).permute(0, 2, 1).contiguous()
+            pending.append((chunk, act.permute(0, 2, 1).contiguous(), xd))
+    for chunk, e_dev, xd_dev in pending:
+        e = e_dev.cpu().numpy()
+        xd = xd_dev.cpu().numpy() if xd_dev is not None else None
+        for i, (u, k, _, _, trunc) in enumerate(chunk):
+            enc_out[(u, k)] = e[i][:trunc] if trunc is not None else e[i]
+            if xd is not None:
+                dec_out[(u, k)] = xd[i]
     encs, decs = [], ([] if decode_speakers is not None else None)
     for u in range(len(specs)):
         ks = sorted(k for (uu, k) in enc_out if uu == u)
