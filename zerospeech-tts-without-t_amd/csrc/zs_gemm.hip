@@ -136,7 +136,7 @@ __device__ __forceinline__ void epilogue_finish(const ZsGemmConv& p, const float
   float* outf = (float*)p.out + (p.out_f32 ? (int64_t)g * p.out_gstride : 0);
   T* outt = (T*)p.out + (p.out_f32 ? 0 : (int64_t)g * p.out_gstride);
 
-#pragma unroll 1
+#pragma unroll 2
   for (int it = 0; it < 8; ++it) {
     const int row = rr0 + ROWS_PER_PASS * it;
     const int m = m0 + row;
