@@ -1162,6 +1162,56 @@ __global__ __launch_bounds__(PNT, 2) void gemm_conv_p8m16_kernel(const ZsGemmCon
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  // Fast epilogue for the common case (bf16 rows out, only bias + activation): every wave applies bias/activation to its
+  // accumulators in registers and stages the WHOLE 256x256 tile as bf16 (132 KiB), so all accumulators are dead at once and
+  // the finish is a pure, deeply unrolled LDS -> global copy with 16-byte accesses (the two-half fp32 path below keeps half
+  // of the accumulators live during its finish and is limited to two rows in flight per thread).
+  if constexpr (sizeof(T) == 2) {
+    const bool fast = p.out != nullptr && !p.out_f32 && p.pre_vec == nullptr && p.dact_src == nullptr && p.add_src == nullptr &&
+                      p.out2 == nullptr && p.store_mode == ZS_STORE_ROWS && (p.act == ZS_ACT_NONE || p.act == ZS_ACT_LRELU) &&
+                      ((((uintptr_t)p.out) | (uintptr_t)(p.ldc * 2) | (uintptr_t)(p.out_gstride * 2)) & 15) == 0 && (p.out_cols & 7) == 0;
+    if (fast) {
+      constexpr int PT = 264;                                       // bf16 pitch: 528-byte rows
+      unsigned short* sT = reinterpret_cast<unsigned short*>(smem);
+      const int colb = wc * 64 + (lane & 15);
+      const int rbase = wr * 128 + 4 * (lane >> 4);
+#pragma unroll
+      for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int col = colb + nq * 32 + nt * 16;
+          const bool cval = n0 + col < p.N;
+          const float bv = (p.bias != nullptr && cval) ? p.bias[(int64_t)g * p.bias_gstride + n0 + col] : 0.f;
+#pragma unroll
+          for (int mq = 0; mq < 2; ++mq)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+              for (int i4 = 0; i4 < 4; ++i4) {
+                float v = c[mq][nq][mt][nt][i4] + bv;
+                if (p.act == ZS_ACT_LRELU) v = lrelu_f(v, p.slope);
+                if (!cval) v = 0.f;                                 // columns [N, out_cols) are written as zeros
+                sT[(rbase + mq * 64 + mt * 16 + i4) * PT + col] = f2bf(v);
+              }
+        }
+      __syncthreads();
+      unsigned short* outp = (unsigned short*)p.out + (int64_t)g * p.out_gstride;
+      const int c8 = (tid & 31) * 8, r0 = tid >> 5;                 // 32 x 16-byte groups per row, 16 rows per pass
+      const int n = n0 + c8;
+      if (n < p.out_cols) {
+#pragma unroll 8
+        for (int it = 0; it < 16; ++it) {
+          const int row = r0 + 16 * it;
+          const int m = m0 + row;
+          if (m < M) {
+            const uint4 w = *reinterpret_cast<const uint4*>(sT + row * PT + c8);
+            *reinterpret_cast<uint4*>(outp + (int64_t)m * p.ldc + n) = w;
+          }
+        }
+      }
+      return;
+    }
+  }
   // epilogue in two 128-column halves through the [256][132] fp32 staging tile
   float* sC = reinterpret_cast<float*>(smem);
 #pragma unroll 1
