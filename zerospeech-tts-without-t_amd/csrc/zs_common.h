@@ -60,6 +60,25 @@ template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float
     v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
   }
 }
+// the same 8 elements kept raw (as loaded) so that a prefetch does not park the wave on the load latency at the load site
+template <typename T> struct Raw8;
+template <> struct Raw8<float> {
+  float4 a, b;
+  __device__ __forceinline__ void ld(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+  __device__ __forceinline__ void zero() { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
+  __device__ __forceinline__ void cvt(float (&v)[8]) const { v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; }
+};
+template <> struct Raw8<bf16_t> {
+  uint4 a;
+  __device__ __forceinline__ void ld(const bf16_t* p) { a = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void zero() { a = make_uint4(0, 0, 0, 0); }
+  __device__ __forceinline__ void cvt(float (&v)[8]) const {
+    const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+};
+
 template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
 template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);

@@ -5,14 +5,23 @@
 // line of a row) of rows t = rg + 32*i.  The per-(b,c) reduction over T happens across the 32 row
 // groups through LDS; values stay in registers between the passes (T <= 256 => <= 8 rows/thread), so
 // each activation is read from HBM exactly once.  These kernels are HBM-bound.
+#include <stdlib.h>
+
 #include "zs_common.h"
 
 namespace {
 
-constexpr int NTN = 256, CHUNK = 64, RG = 32, RPT = 8;   // threads, channels/WG, row groups, rows/thread
+constexpr int RPT = 8;                                   // rows per thread
+// Two shapes of the same decomposition (threads NTN, channels per workgroup CHUNK = NTN/RG*8, row groups RG):
+//   narrow: 256 threads, 64 channels (128 B of a row per workgroup), 32 row groups -> T <= 256
+//   wide  : 512 threads, 256 channels (512 B of a row per workgroup: 4x longer DRAM bursts), 16 row groups -> T <= 128
+struct Narrow { static constexpr int NTN = 256, CHUNK = 64, RG = 32; };
+struct Wide { static constexpr int NTN = 512, CHUNK = 256, RG = 16; };
 
-// sum the per-thread partial p[8] of channel group cg across the 32 row groups; result broadcast.
+// sum the per-thread partial p[8] of channel group cg across the row groups; result broadcast.
+template <typename S>
 __device__ __forceinline__ void colreduce(float (&pv)[8], float* red, float* tot, int cg, int rg, int tid) {
+  constexpr int CHUNK = S::CHUNK, RG = S::RG;
 #pragma unroll
   for (int k = 0; k < 8; ++k) red[rg * CHUNK + cg * 8 + k] = pv[k];
   __syncthreads();
@@ -37,31 +46,49 @@ __device__ __forceinline__ float keep_scale(const uint8_t* mask, int64_t mask_ld
   return keep ? inv_keep : 0.f;
 }
 
-template <typename T>
-__global__ __launch_bounds__(NTN) void instnorm_fwd_kernel(const ZsInstNormFwd p) {
+template <typename T, typename S>
+__global__ __launch_bounds__(S::NTN) void instnorm_fwd_kernel(const ZsInstNormFwd p) {
+  constexpr int CHUNK = S::CHUNK, RG = S::RG, CGN = S::CHUNK / 8;
   __shared__ float red[RG * CHUNK];
   __shared__ float tot[CHUNK];
-  const int tid = threadIdx.x, cg = tid & 7, rg = tid >> 3;
+  const int tid = threadIdx.x, cg = tid % CGN, rg = tid / CGN;
   const int b = blockIdx.y, c0 = blockIdx.x * CHUNK + cg * 8;
   const bool cvalid = c0 < p.C;
   const T* x = (const T*)p.x;
-  float v[RPT][8];
+  Raw8<T> v[RPT];            // rows stay as loaded (bf16: 4 registers per 8 values instead of 8) between the passes: occupancy
   float s[8];
+  // the residual rows are fetched together with x (raw: they are not needed before the second pass), so that their HBM
+  // latency is not paid again behind the two reductions
+  const T* res = (const T*)p.res;
+  Raw8<T> rr0[RPT];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int t = rg + RG * i;
+    rr0[i].zero();
+    if (cvalid && t < p.T) {
+      if (p.res_mode == ZS_RES_IDENTITY) rr0[i].ld(res + ((int64_t)b * p.T + t) * p.ldres + c0);
+      else if (p.res_mode == ZS_RES_UPSAMPLE2) rr0[i].ld(res + ((int64_t)b * p.T_res + (t >> 1)) * p.ldres + c0);
+      else if (p.res_mode == ZS_RES_AVGPOOL2) {
+        // F.pad(x, (0, T%2), reflect|constant) + avg_pool1d(2)   (model/model.py:424-425)
+        rr0[i].ld(res + ((int64_t)b * p.T_res + 2 * t) * p.ldres + c0);     // the odd partner row is fetched in the second pass
+      }
+    }
+  }
 #pragma unroll
   for (int k = 0; k < 8; ++k) s[k] = 0.f;
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
     const int t = rg + RG * i;
-    if (cvalid && t < p.T) {
-      load8<T>(x + ((int64_t)b * p.T + t) * p.ldx + c0, v[i]);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) s[k] += v[i][k];
-    } else {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[i][k] = 0.f;
-    }
+    v[i].zero();
+    if (cvalid && t < p.T) v[i].ld(x + ((int64_t)b * p.T + t) * p.ldx + c0);
   }
-  colreduce(s, red, tot, cg, rg, tid);
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    float f[8]; v[i].cvt(f);                      // rows past T are zeros
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] += f[k];
+  }
+  colreduce<S>(s, red, tot, cg, rg, tid);
   float mean[8], q[8];
   const float invT = 1.f / (float)p.T;
 #pragma unroll
@@ -70,11 +97,12 @@ __global__ __launch_bounds__(NTN) void instnorm_fwd_kernel(const ZsInstNormFwd p
   for (int i = 0; i < RPT; ++i) {
     const int t = rg + RG * i;
     if (t < p.T) {
+      float f[8]; v[i].cvt(f);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mean[k]; q[k] += d * d; }
+      for (int k = 0; k < 8; ++k) { const float d = f[k] - mean[k]; q[k] += d * d; }
     }
   }
-  colreduce(q, red, tot, cg, rg, tid);
+  colreduce<S>(q, red, tot, cg, rg, tid);
   float rstd[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) rstd[k] = 1.f / sqrtf(q[k] * invT + p.eps);
@@ -91,30 +119,24 @@ __global__ __launch_bounds__(NTN) void instnorm_fwd_kernel(const ZsInstNormFwd p
 #pragma unroll
     for (int k = 0; k < 8; ++k) e2[k] = (p.vec2 && (c0 + k) < p.vec2_cols) ? p.vec2[vi * p.vec2_ld + c0 + k] : 0.f;
   }
-  const T* res = (const T*)p.res;
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
     const int t = rg + RG * i;
     if (t >= p.T) continue;
     const int64_t row = (int64_t)b * p.T + t;
-    float o[8];
+    float o[8], f[8];
+    v[i].cvt(f);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      o[k] = (v[i][k] - mean[k]) * rstd[k];
+      o[k] = (f[k] - mean[k]) * rstd[k];
       o[k] *= keep_scale(p.mask, p.mask_ld, p.drop_p, seed, p.stream_id, row, c0 + k, p.C, inv_keep);
     }
-    if (p.res_mode == ZS_RES_IDENTITY) {
-      float r[8]; load8<T>(res + row * p.ldres + c0, r);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) o[k] += r[k];
-    } else if (p.res_mode == ZS_RES_UPSAMPLE2) {
-      float r[8]; load8<T>(res + ((int64_t)b * p.T_res + (t >> 1)) * p.ldres + c0, r);
+    if (p.res_mode == ZS_RES_IDENTITY || p.res_mode == ZS_RES_UPSAMPLE2) {
+      float r[8]; rr0[i].cvt(r);
 #pragma unroll
       for (int k = 0; k < 8; ++k) o[k] += r[k];
     } else if (p.res_mode == ZS_RES_AVGPOOL2) {
-      // F.pad(x, (0, T%2), reflect|constant) + avg_pool1d(2)   (model/model.py:424-425)
-      float r0[8], r1[8];
-      load8<T>(res + ((int64_t)b * p.T_res + 2 * t) * p.ldres + c0, r0);
+      float r0[8], r1[8]; rr0[i].cvt(r0);
       int t1 = 2 * t + 1; bool have = true;
       if (t1 >= p.T_res) { if (p.res_pad_mode == ZS_PAD_REFLECT) t1 = p.T_res - 2; else have = false; }
       if (have) load8<T>(res + ((int64_t)b * p.T_res + t1) * p.ldres + c0, r1);
@@ -134,11 +156,12 @@ __global__ __launch_bounds__(NTN) void instnorm_fwd_kernel(const ZsInstNormFwd p
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(NTN) void instnorm_bwd_kernel(const ZsInstNormBwd p) {
+template <typename T, typename S>
+__global__ __launch_bounds__(S::NTN) void instnorm_bwd_kernel(const ZsInstNormBwd p) {
+  constexpr int CHUNK = S::CHUNK, RG = S::RG, CGN = S::CHUNK / 8;
   __shared__ float red[RG * CHUNK];
   __shared__ float tot[CHUNK];
-  const int tid = threadIdx.x, cg = tid & 7, rg = tid >> 3;
+  const int tid = threadIdx.x, cg = tid % CGN, rg = tid / CGN;
   const int b = blockIdx.y, c0 = blockIdx.x * CHUNK + cg * 8;
   const bool cvalid = c0 < p.C;
   float mean[8], rstd[8];
@@ -149,30 +172,37 @@ __global__ __launch_bounds__(NTN) void instnorm_bwd_kernel(const ZsInstNormBwd p
   }
   const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
   const uint64_t seed = p.seed + (p.seed_ptr ? *p.seed_ptr : 0ull);
-  float g[RPT][8], xv[RPT][8];
+  Raw8<T> g[RPT], xv[RPT];      // as loaded: 8 instead of 16 registers per row pair in bf16 (this kernel was at 256 VGPRs)
   float sg[8], sgx[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { sg[k] = 0.f; sgx[k] = 0.f; }
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
     const int t = rg + RG * i;
+    g[i].zero(); xv[i].zero();
     if (cvalid && t < p.T) {
       const int64_t row = (int64_t)b * p.T + t;
-      load8<T>((const T*)p.dout + row * p.ldd + c0, g[i]);
-      load8<T>((const T*)p.x + row * p.ldx + c0, xv[i]);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        g[i][k] *= keep_scale(p.mask, p.mask_ld, p.drop_p, seed, p.stream_id, row, c0 + k, p.C, inv_keep);
-        const float xh = (xv[i][k] - mean[k]) * rstd[k];
-        sg[k] += g[i][k]; sgx[k] += g[i][k] * xh;
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { g[i][k] = 0.f; xv[i][k] = 0.f; }
+      g[i].ld((const T*)p.dout + row * p.ldd + c0);
+      xv[i].ld((const T*)p.x + row * p.ldx + c0);
     }
   }
-  colreduce(sg, red, tot, cg, rg, tid);
-  colreduce(sgx, red, tot, cg, rg, tid);
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int t = rg + RG * i;
+    if (cvalid && t < p.T) {
+      const int64_t row = (int64_t)b * p.T + t;
+      float gf[8], xf[8];
+      g[i].cvt(gf); xv[i].cvt(xf);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        gf[k] *= keep_scale(p.mask, p.mask_ld, p.drop_p, seed, p.stream_id, row, c0 + k, p.C, inv_keep);
+        const float xh = (xf[k] - mean[k]) * rstd[k];
+        sg[k] += gf[k]; sgx[k] += gf[k] * xh;
+      }
+    }
+  }
+  colreduce<S>(sg, red, tot, cg, rg, tid);
+  colreduce<S>(sgx, red, tot, cg, rg, tid);
   if (!cvalid) return;
   const float invT = 1.f / (float)p.T;
 #pragma unroll
@@ -180,22 +210,25 @@ __global__ __launch_bounds__(NTN) void instnorm_bwd_kernel(const ZsInstNormBwd p
     const int t = rg + RG * i;
     if (t >= p.T) continue;
     const int64_t row = (int64_t)b * p.T + t;
-    float o[8];
+    float o[8], gf[8], xf[8];
+    g[i].cvt(gf); xv[i].cvt(xf);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float xh = (xv[i][k] - mean[k]) * rstd[k];
-      const float dx = rstd[k] * (g[i][k] - sg[k] * invT - xh * (sgx[k] * invT));
-      o[k] = dx * dlrelu_f(xv[i][k], p.slope);
+      gf[k] *= keep_scale(p.mask, p.mask_ld, p.drop_p, seed, p.stream_id, row, c0 + k, p.C, inv_keep);   // same mask as in the first pass
+      const float xh = (xf[k] - mean[k]) * rstd[k];
+      const float dx = rstd[k] * (gf[k] - sg[k] * invT - xh * (sgx[k] * invT));
+      o[k] = dx * dlrelu_f(xf[k], p.slope);
     }
     store8<T>((T*)p.dz + row * p.ldz + c0, o);
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(NTN) void grad_combine_kernel(const ZsGradCombine p) {
+template <typename T, typename S>
+__global__ __launch_bounds__(S::NTN) void grad_combine_kernel(const ZsGradCombine p) {
+  constexpr int CHUNK = S::CHUNK, RG = S::RG, CGN = S::CHUNK / 8;
   __shared__ float red[RG * CHUNK];
   __shared__ float tot[CHUNK];
-  const int tid = threadIdx.x, cg = tid & 7, rg = tid >> 3;
+  const int tid = threadIdx.x, cg = tid % CGN, rg = tid / CGN;
   const int b = blockIdx.y, c0 = blockIdx.x * CHUNK + cg * 8;
   const bool cvalid = c0 < p.C;
   const int Tp = p.T + p.pad_left + p.pad_right;
@@ -229,7 +262,7 @@ __global__ __launch_bounds__(NTN) void grad_combine_kernel(const ZsGradCombine p
     }
   }
   if (p.emb_sum) {                                             // uniform branch
-    colreduce(s, red, tot, cg, rg, tid);
+    colreduce<S>(s, red, tot, cg, rg, tid);
     if (cvalid && rg == 0) {                                   // this workgroup owns (b, these channels): plain RMW
 #pragma unroll
       for (int k = 0; k < 8; ++k)
@@ -273,6 +306,7 @@ __global__ __launch_bounds__(NTN) void grad_combine_kernel(const ZsGradCombine p
 }
 
 bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+bool norm_wide() { static int v = -1; if (v < 0) { const char* e = getenv("ZS_NORM_WIDE"); v = e ? atoi(e) : 1; } return v != 0; }
 
 }  // namespace
 
@@ -280,7 +314,7 @@ extern "C" int zs_instnorm_fwd(const ZsInstNormFwd* p, void* stream) {
   ZS_REQUIRE(p && p->x && p->out, "zs_instnorm_fwd: null operand");
   ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_instnorm_fwd: bad dtype");
   const int es = p->dtype == ZS_F32 ? 4 : 2;
-  ZS_REQUIRE(p->B > 0 && p->T > 0 && p->T <= RG * RPT && p->C > 0 && p->C % 8 == 0, "zs_instnorm_fwd: need 0<T<=256 (T=%d), C%%8==0 (C=%d)", p->T, p->C);
+  ZS_REQUIRE(p->B > 0 && p->T > 0 && p->T <= Narrow::RG * RPT && p->C > 0 && p->C % 8 == 0, "zs_instnorm_fwd: need 0<T<=256 (T=%d), C%%8==0 (C=%d)", p->T, p->C);
   ZS_REQUIRE(al16(p->x) && al16(p->out) && (p->ldx * es) % 16 == 0 && (p->ldo * es) % 16 == 0, "zs_instnorm_fwd: alignment");
   ZS_REQUIRE(!p->out2 || (al16(p->out2) && (p->ldo2 * es) % 16 == 0 && (!p->vec2 || p->idx)), "zs_instnorm_fwd: out2");
   ZS_REQUIRE((p->mean == nullptr) == (p->rstd == nullptr), "zs_instnorm_fwd: mean/rstd");
@@ -290,9 +324,15 @@ extern "C" int zs_instnorm_fwd(const ZsInstNormFwd* p, void* stream) {
     if (p->res_mode == ZS_RES_AVGPOOL2) ZS_REQUIRE((p->T_res + 1) / 2 == p->T && p->T_res >= 2, "zs_instnorm_fwd: avgpool T_res %d vs T %d", p->T_res, p->T);
   }
   ZS_REQUIRE(p->drop_p >= 0.f && p->drop_p < 1.f, "zs_instnorm_fwd: drop_p");
-  dim3 grid((p->C + CHUNK - 1) / CHUNK, p->B);
-  if (p->dtype == ZS_F32) hipLaunchKernelGGL(instnorm_fwd_kernel<float>, grid, dim3(NTN), 0, (hipStream_t)stream, *p);
-  else hipLaunchKernelGGL(instnorm_fwd_kernel<bf16_t>, grid, dim3(NTN), 0, (hipStream_t)stream, *p);
+  if (p->T <= Wide::RG * RPT && p->C >= Wide::CHUNK && norm_wide()) {
+    dim3 grid((p->C + Wide::CHUNK - 1) / Wide::CHUNK, p->B);
+    if (p->dtype == ZS_F32) hipLaunchKernelGGL((instnorm_fwd_kernel<float, Wide>), grid, dim3(Wide::NTN), 0, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL((instnorm_fwd_kernel<bf16_t, Wide>), grid, dim3(Wide::NTN), 0, (hipStream_t)stream, *p);
+  } else {
+    dim3 grid((p->C + Narrow::CHUNK - 1) / Narrow::CHUNK, p->B);
+    if (p->dtype == ZS_F32) hipLaunchKernelGGL((instnorm_fwd_kernel<float, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL((instnorm_fwd_kernel<bf16_t, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);
+  }
   return zs_check_launch("zs_instnorm_fwd");
 }
 
@@ -300,12 +340,18 @@ extern "C" int zs_instnorm_bwd(const ZsInstNormBwd* p, void* stream) {
   ZS_REQUIRE(p && p->dout && p->x && p->mean && p->rstd && p->dz, "zs_instnorm_bwd: null operand");
   ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_instnorm_bwd: bad dtype");
   const int es = p->dtype == ZS_F32 ? 4 : 2;
-  ZS_REQUIRE(p->B > 0 && p->T > 0 && p->T <= RG * RPT && p->C > 0 && p->C % 8 == 0, "zs_instnorm_bwd: sizes");
+  ZS_REQUIRE(p->B > 0 && p->T > 0 && p->T <= Narrow::RG * RPT && p->C > 0 && p->C % 8 == 0, "zs_instnorm_bwd: sizes");
   ZS_REQUIRE(al16(p->dout) && al16(p->x) && al16(p->dz) && (p->ldd * es) % 16 == 0 && (p->ldx * es) % 16 == 0 && (p->ldz * es) % 16 == 0,
              "zs_instnorm_bwd: alignment");
-  dim3 grid((p->C + CHUNK - 1) / CHUNK, p->B);
-  if (p->dtype == ZS_F32) hipLaunchKernelGGL(instnorm_bwd_kernel<float>, grid, dim3(NTN), 0, (hipStream_t)stream, *p);
-  else hipLaunchKernelGGL(instnorm_bwd_kernel<bf16_t>, grid, dim3(NTN), 0, (hipStream_t)stream, *p);
+  if (p->T <= Wide::RG * RPT && p->C >= Wide::CHUNK && norm_wide()) {
+    dim3 grid((p->C + Wide::CHUNK - 1) / Wide::CHUNK, p->B);
+    if (p->dtype == ZS_F32) hipLaunchKernelGGL((instnorm_bwd_kernel<float, Wide>), grid, dim3(Wide::NTN), 0, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL((instnorm_bwd_kernel<bf16_t, Wide>), grid, dim3(Wide::NTN), 0, (hipStream_t)stream, *p);
+  } else {
+    dim3 grid((p->C + Narrow::CHUNK - 1) / Narrow::CHUNK, p->B);
+    if (p->dtype == ZS_F32) hipLaunchKernelGGL((instnorm_bwd_kernel<float, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL((instnorm_bwd_kernel<bf16_t, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);
+  }
   return zs_check_launch("zs_instnorm_bwd");
 }
 
@@ -313,7 +359,7 @@ extern "C" int zs_grad_combine(const ZsGradCombine* p, void* stream) {
   ZS_REQUIRE(p && p->gp && (p->out || p->emb_sum), "zs_grad_combine: null operand");
   ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_grad_combine: bad dtype");
   const int es = p->dtype == ZS_F32 ? 4 : 2;
-  ZS_REQUIRE(p->B > 0 && p->T > 0 && p->T <= RG * RPT && p->C > 0 && p->C % 8 == 0, "zs_grad_combine: sizes T=%d C=%d", p->T, p->C);
+  ZS_REQUIRE(p->B > 0 && p->T > 0 && p->T <= Narrow::RG * RPT && p->C > 0 && p->C % 8 == 0, "zs_grad_combine: sizes T=%d C=%d", p->T, p->C);
   ZS_REQUIRE(p->pad_left >= 0 && p->pad_right >= 0 && (p->pad_mode != ZS_PAD_REFLECT || (p->pad_left < p->T && p->pad_right < p->T)),
              "zs_grad_combine: pads");
   ZS_REQUIRE(al16(p->gp) && (p->ldg * es) % 16 == 0 && (!p->out || (al16(p->out) && (p->ldo * es) % 16 == 0)), "zs_grad_combine: alignment");
@@ -323,8 +369,14 @@ extern "C" int zs_grad_combine(const ZsGradCombine* p, void* stream) {
   }
   ZS_REQUIRE(!p->unshuffle || (p->T % 2 == 0 && (p->C * es) % 16 == 0), "zs_grad_combine: unshuffle");
   ZS_REQUIRE(!p->dact_src || (al16(p->dact_src) && (p->dact_ld * es) % 16 == 0), "zs_grad_combine: dact");
-  dim3 grid((p->C + CHUNK - 1) / CHUNK, p->B);
-  if (p->dtype == ZS_F32) hipLaunchKernelGGL(grad_combine_kernel<float>, grid, dim3(NTN), 0, (hipStream_t)stream, *p);
-  else hipLaunchKernelGGL(grad_combine_kernel<bf16_t>, grid, dim3(NTN), 0, (hipStream_t)stream, *p);
+  if (p->T <= Wide::RG * RPT && p->C >= Wide::CHUNK && norm_wide()) {
+    dim3 grid((p->C + Wide::CHUNK - 1) / Wide::CHUNK, p->B);
+    if (p->dtype == ZS_F32) hipLaunchKernelGGL((grad_combine_kernel<float, Wide>), grid, dim3(Wide::NTN), 0, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL((grad_combine_kernel<bf16_t, Wide>), grid, dim3(Wide::NTN), 0, (hipStream_t)stream, *p);
+  } else {
+    dim3 grid((p->C + Narrow::CHUNK - 1) / Narrow::CHUNK, p->B);
+    if (p->dtype == ZS_F32) hipLaunchKernelGGL((grad_combine_kernel<float, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL((grad_combine_kernel<bf16_t, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);
+  }
   return zs_check_launch("zs_grad_combine");
 }
