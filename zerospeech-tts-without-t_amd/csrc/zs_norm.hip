@@ -12,11 +12,10 @@
 namespace {
 
 constexpr int RPT = 8;                                   // rows per thread
-// Two shapes of the same decomposition (threads NTN, channels per workgroup CHUNK = NTN/RG*8, row groups RG):
-//   narrow: 256 threads, 64 channels (128 B of a row per workgroup), 32 row groups -> T <= 256
-//   wide  : 512 threads, 256 channels (512 B of a row per workgroup: 4x longer DRAM bursts), 16 row groups -> T <= 128
+// The decomposition (threads NTN, channels per workgroup CHUNK = NTN/RG*8, row groups RG): 256 threads, 64 channels (128 B
+// of a row per workgroup), 32 row groups -> T <= 256.  A 512-thread / 256-channel variant (512 B of a row per workgroup)
+// measured slower in isolation (instnorm_bwd 62 vs 41 us at [256,128,1024]) and equal inside the step.
 struct Narrow { static constexpr int NTN = 256, CHUNK = 64, RG = 32; };
-struct Wide { static constexpr int NTN = 512, CHUNK = 256, RG = 16; };
 
 // sum the per-thread partial p[8] of channel group cg across the row groups; result broadcast.
 template <typename S>
@@ -306,7 +305,6 @@ __global__ __launch_bounds__(S::NTN) void grad_combine_kernel(const ZsGradCombin
 }
 
 bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
-bool norm_wide() { static int v = -1; if (v < 0) { const char* e = getenv("ZS_NORM_WIDE"); v = e ? atoi(e) : 1; } return v != 0; }
 
 }  // namespace
 
@@ -324,15 +322,9 @@ extern "C" int zs_instnorm_fwd(const ZsInstNormFwd* p, void* stream) {
     if (p->res_mode == ZS_RES_AVGPOOL2) ZS_REQUIRE((p->T_res + 1) / 2 == p->T && p->T_res >= 2, "zs_instnorm_fwd: avgpool T_res %d vs T %d", p->T_res, p->T);
   }
   ZS_REQUIRE(p->drop_p >= 0.f && p->drop_p < 1.f, "zs_instnorm_fwd: drop_p");
-  if (p->T <= Wide::RG * RPT && p->C >= Wide::CHUNK && norm_wide()) {
-    dim3 grid((p->C + Wide::CHUNK - 1) / Wide::CHUNK, p->B);
-    if (p->dtype == ZS_F32) hipLaunchKernelGGL((instnorm_fwd_kernel<float, Wide>), grid, dim3(Wide::NTN), 0, (hipStream_t)stream, *p);
-    else hipLaunchKernelGGL((instnorm_fwd_kernel<bf16_t, Wide>), grid, dim3(Wide::NTN), 0, (hipStream_t)stream, *p);
-  } else {
-    dim3 grid((p->C + Narrow::CHUNK - 1) / Narrow::CHUNK, p->B);
-    if (p->dtype == ZS_F32) hipLaunchKernelGGL((instnorm_fwd_kernel<float, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);
-    else hipLaunchKernelGGL((instnorm_fwd_kernel<bf16_t, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);
-  }
+  dim3 grid((p->C + Narrow::CHUNK - 1) / Narrow::CHUNK, p->B);
+  if (p->dtype == ZS_F32) hipLaunchKernelGGL((instnorm_fwd_kernel<float, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);
+  else hipLaunchKernelGGL((instnorm_fwd_kernel<bf16_t, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);
   return zs_check_launch("zs_instnorm_fwd");
 }
 
@@ -343,15 +335,9 @@ extern "C" int zs_instnorm_bwd(const ZsInstNormBwd* p, void* stream) {
   ZS_REQUIRE(p->B > 0 && p->T > 0 && p->T <= Narrow::RG * RPT && p->C > 0 && p->C % 8 == 0, "zs_instnorm_bwd: sizes");
   ZS_REQUIRE(al16(p->dout) && al16(p->x) && al16(p->dz) && (p->ldd * es) % 16 == 0 && (p->ldx * es) % 16 == 0 && (p->ldz * es) % 16 == 0,
              "zs_instnorm_bwd: alignment");
-  if (p->T <= Wide::RG * RPT && p->C >= Wide::CHUNK && norm_wide()) {
-    dim3 grid((p->C + Wide::CHUNK - 1) / Wide::CHUNK, p->B);
-    if (p->dtype == ZS_F32) hipLaunchKernelGGL((instnorm_bwd_kernel<float, Wide>), grid, dim3(Wide::NTN), 0, (hipStream_t)stream, *p);
-    else hipLaunchKernelGGL((instnorm_bwd_kernel<bf16_t, Wide>), grid, dim3(Wide::NTN), 0, (hipStream_t)stream, *p);
-  } else {
-    dim3 grid((p->C + Narrow::CHUNK - 1) / Narrow::CHUNK, p->B);
-    if (p->dtype == ZS_F32) hipLaunchKernelGGL((instnorm_bwd_kernel<float, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);
-    else hipLaunchKernelGGL((instnorm_bwd_kernel<bf16_t, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);
-  }
+  dim3 grid((p->C + Narrow::CHUNK - 1) / Narrow::CHUNK, p->B);
+  if (p->dtype == ZS_F32) hipLaunchKernelGGL((instnorm_bwd_kernel<float, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);
+  else hipLaunchKernelGGL((instnorm_bwd_kernel<bf16_t, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);
   return zs_check_launch("zs_instnorm_bwd");
 }
 
@@ -369,14 +355,8 @@ extern "C" int zs_grad_combine(const ZsGradCombine* p, void* stream) {
   }
   ZS_REQUIRE(!p->unshuffle || (p->T % 2 == 0 && (p->C * es) % 16 == 0), "zs_grad_combine: unshuffle");
   ZS_REQUIRE(!p->dact_src || (al16(p->dact_src) && (p->dact_ld * es) % 16 == 0), "zs_grad_combine: dact");
-  if (p->T <= Wide::RG * RPT && p->C >= Wide::CHUNK && norm_wide()) {
-    dim3 grid((p->C + Wide::CHUNK - 1) / Wide::CHUNK, p->B);
-    if (p->dtype == ZS_F32) hipLaunchKernelGGL((grad_combine_kernel<float, Wide>), grid, dim3(Wide::NTN), 0, (hipStream_t)stream, *p);
-    else hipLaunchKernelGGL((grad_combine_kernel<bf16_t, Wide>), grid, dim3(Wide::NTN), 0, (hipStream_t)stream, *p);
-  } else {
-    dim3 grid((p->C + Narrow::CHUNK - 1) / Narrow::CHUNK, p->B);
-    if (p->dtype == ZS_F32) hipLaunchKernelGGL((grad_combine_kernel<float, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);
-    else hipLaunchKernelGGL((grad_combine_kernel<bf16_t, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);
-  }
+  dim3 grid((p->C + Narrow::CHUNK - 1) / Narrow::CHUNK, p->B);
+  if (p->dtype == ZS_F32) hipLaunchKernelGGL((grad_combine_kernel<float, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);
+  else hipLaunchKernelGGL((grad_combine_kernel<bf16_t, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);
   return zs_check_launch("zs_grad_combine");
 }
