@@ -349,6 +349,23 @@ typedef struct {
 } ZsGlStft;
 int zs_gl_stft_project(const ZsGlStft* p, void* stream);
 /* spectrogram2wav pre/post (convert.py:56-60): de-normalise to amplitude; de-preemphasis IIR. */
+/* ---------------------------------------------------------------------------------------------
+ * Feature extraction feeding the path (preprocess.py:227-258 get_spectrograms after the host-side
+ * librosa.effects.trim): wav [n_utt][wav_ld] fp32, n_samples[u] valid samples ->
+ *   mag[u][t][0..513) = clip((20 log10(max(1e-5, |STFT(preemph(y))|)) - ref_db + max_db) / max_db, 1e-8, 1), t < 1 + n_samples/200
+ *   amp (optional, [n_utt][T_max][513]): the linear magnitudes, input of zs_pre_mel.
+ * STFT as in the vocoder: n_fft 1024, hop 200, hann(800) centred, reflect-padded centre frames.
+ */
+typedef struct {
+  const float* wav; int64_t wav_ld; const int32_t* n_samples; int32_t n_utt, T_max;
+  float preemph, ref_db, max_db;
+  float* mag; int64_t mag_ld;      /* [n_utt][T_max][mag_ld], mag_ld >= 513 */
+  float* amp;
+} ZsPreSpec;
+int zs_pre_spectrogram(const ZsPreSpec* p, void* stream);
+/* mel[r][m] = clip((20 log10(max(1e-5, sum_k basis[m][k] amp[r][k])) - ref_db + max_db) / max_db, 1e-8, 1); basis [n_mels][513]
+ * (librosa.filters.mel(sr, n_fft, n_mels), preprocess.py:243-252) */
+int zs_pre_mel(const float* amp, const float* basis, float* mel, int64_t rows, int32_t n_mels, float ref_db, float max_db, void* stream);
 int zs_gl_denormalize(const float* mag_norm, float* mag_amp, int64_t n, void* stream);
 int zs_gl_deemphasis(float* wav, int64_t wav_ld, const int32_t* lengths, int32_t n_utt, float coef, void* stream);
 

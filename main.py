@@ -1,11 +1,12 @@
 """Command line of the autoencoder hot path, with the reference's flag names (main.py:27-79):
 
+  python main.py --preprocess [--remake]                  (wav directories -> dataset container + index JSONs)
   python main.py --train_ae [--load_model] [--hps_path hps/zerospeech_english_1024.json] [--synthetic]
   python main.py --test --enc_only | --test_encode        (needs the preprocessed HDF5 + a checkpoint)
 
 Multi-GPU training: `python -m torch.distributed.run --nproc-per-node N main.py --train_ae ...` (one
 process per GPU; gradients are averaged with RCCL).  Modes outside the stage-1 autoencoder path
-(--preprocess, --train_p, --train_tgat, --train_al, --train_c, --train_t, --cross_test, --test_single,
+(--train_p, --train_tgat, --train_al, --train_c, --train_t, --cross_test, --test_single,
 --test_classify, --encode, --test_asr) are not part of this build and exit with a clear error.
 """
 import argparse
@@ -15,13 +16,13 @@ import sys
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-OUT_OF_SCOPE = ['preprocess', 'train_p', 'train_tgat', 'train_al', 'train_c', 'train_t', 'test_asr', 'cross_test', 'test_single',
+OUT_OF_SCOPE = ['train_p', 'train_tgat', 'train_al', 'train_c', 'train_t', 'test_asr', 'cross_test', 'test_single',
                 'test_classify', 'encode']
 
 
 def build_parser():
     p = argparse.ArgumentParser(description='zerospeech_project (MI355X autoencoder hot path)')
-    for flag in ['train', 'train_ae', 'test', 'test_encode', 'load_model', 'enc_only', 'remake', 'synthetic'] + OUT_OF_SCOPE:
+    for flag in ['preprocess', 'train', 'train_ae', 'test', 'test_encode', 'load_model', 'enc_only', 'remake', 'synthetic'] + OUT_OF_SCOPE:
         p.add_argument('--' + flag, default=False, action='store_true')
     p.add_argument('--flag', type=str, default='train')
     p.add_argument('--g_mode', default='set_from_hps',
@@ -30,10 +31,14 @@ def build_parser():
                    choices=['continues', 'one_hot', 'binary', 'multilabel_binary', 'gumbel_t', 'set_from_hps'])
     p.add_argument('--dataset', choices=['english', 'surprise'], default='english')
     p.add_argument('--dtype', choices=['fp32', 'bf16'], default=os.environ.get('ZS_DTYPE', 'bf16'))
+    p.add_argument('--source_path', type=str, default='./data/english/train/unit/')
+    p.add_argument('--target_path', type=str, default='./data/english/train/voice/')
     p.add_argument('--test_path', type=str, default='./data/english/test/')
     p.add_argument('--synthesis_list', type=str, default='./data/english/synthesis.txt')
     p.add_argument('--dataset_path', type=str, default='./data/dataset_english.hdf5')
     p.add_argument('--index_path', type=str, default='./data/index_english.json')
+    p.add_argument('--index_source_path', type=str, default='./data/index_english_source.json')
+    p.add_argument('--index_target_path', type=str, default='./data/index_english_target.json')
     p.add_argument('--speaker2id_path', type=str, default='./data/speaker2id_english.json')
     p.add_argument('--hps_path', type=str, default='./hps/zerospeech_english.json')
     p.add_argument('--ckpt_dir', type=str, default='./ckpt_english')
@@ -79,6 +84,12 @@ def main(argv=None):
     from zs_amd.convert import get_trainer, test_encode, test_from_list
     from zs_amd.dataloader import DataLoader, Dataset, SyntheticDataset
     from zs_amd.trainer import Trainer
+
+    if args.preprocess:                                   # main.py:113-126
+        from zs_amd.preprocess import preprocess
+        preprocess(args.source_path, args.target_path, args.test_path, args.dataset_path, args.index_path, args.index_source_path,
+                   args.index_target_path, args.speaker2id_path, seg_len=hps.seg_len, n_samples=hps.n_samples, dset=args.flag,
+                   remake=args.remake)
 
     if args.train or args.train_ae:
         rank, world, _ = parallel.init_from_env()

@@ -469,3 +469,56 @@ def spectrogram2wav(mag_tf, n_iter=N_ITER, do_trim=True):
     if do_trim:
         wav, _ = trim(wav)
     return wav.astype(np.float32)
+
+
+# ---- feature extraction (preprocess.py:227-258), SURVEY 8(f) item 3 -------------------------------------------------
+# PARITY UNPINNED: librosa is not installed and the reference pins no version (its call style implies <= 0.7); the mel
+# filterbank and the trim are restated from librosa's documented semantics (Slaney mel scale, area normalisation).
+N_MELS = 80
+
+
+def _hz_to_mel(f):
+    f = np.asarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    mels = f / f_sp
+    min_log_hz, logstep = 1000.0, np.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-12) / min_log_hz) / logstep, mels)
+
+
+def _mel_to_hz(m):
+    m = np.asarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz, logstep = 1000.0, np.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def mel_basis(sr=SR, n_fft=N_FFT, n_mels=N_MELS):
+    """librosa.filters.mel(sr, n_fft, n_mels) (htk=False, norm='slaney', fmin 0, fmax sr/2): float32 [n_mels, 1 + n_fft//2]."""
+    fft_f = np.linspace(0, sr / 2.0, 1 + n_fft // 2)
+    mel_f = _mel_to_hz(np.linspace(_hz_to_mel(0.0), _hz_to_mel(sr / 2.0), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fft_f[None, :]
+    w = np.zeros((n_mels, 1 + n_fft // 2))
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        w[i] = np.maximum(0, np.minimum(lower, upper))
+    w *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return w.astype(np.float32)
+
+
+def get_spectrograms(y, do_trim=True):
+    """preprocess.py:237-258 on an already loaded 16 kHz waveform: (mel [T, 80], mag [T, 513]) float32."""
+    y = np.asarray(y, dtype=np.float32)
+    if do_trim:
+        y = trim(y)[0].astype(np.float32)
+    y = np.append(y[0], y[1:] - PREEMPH * y[:-1]).astype(np.float32)
+    mag = np.abs(stft(y))                                                      # [513, T]
+    mel = mel_basis() @ mag
+    mel = 20 * np.log10(np.maximum(1e-5, mel))
+    mag = 20 * np.log10(np.maximum(1e-5, mag))
+    mel = np.clip((mel - REF_DB + MAX_DB) / MAX_DB, 1e-8, 1)
+    mag = np.clip((mag - REF_DB + MAX_DB) / MAX_DB, 1e-8, 1)
+    return mel.T.astype(np.float32), mag.T.astype(np.float32)

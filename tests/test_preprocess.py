@@ -1,0 +1,118 @@
+"""feature extraction (preprocess.py:227-258) and the dataset / index files feeding --train_ae.
+PARITY UNPINNED for the librosa pieces (mel filterbank, trim, STFT): librosa is not installed and the reference pins no
+version; the checker is the oracle's restatement of librosa's documented semantics (oracle/zs_oracle.py)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+
+
+def _tone_wav(rng, n, silence=0):
+    t = np.arange(n) / 16000.0
+    y = 0.3 * np.sin(2 * np.pi * rng.uniform(100, 3000) * t) + 0.1 * np.sin(2 * np.pi * rng.uniform(3000, 7000) * t)
+    y = y + 0.02 * rng.randn(n)
+    if silence:
+        y[:silence] *= 1e-5
+        y[-silence:] *= 1e-5
+    return y.astype(np.float32)
+
+
+def test_mel_basis_matches_oracle_and_is_a_slaney_filterbank():
+    import zs_oracle as O
+    import zs_amd  # noqa: F401
+    from zs_amd import preprocess as P
+    b = P.mel_basis()
+    assert b.shape == (80, 513) and b.dtype == np.float32
+    assert np.array_equal(b, O.mel_basis())
+    assert (b >= 0).all() and (b.sum(axis=1) > 0).all()
+    peaks = b.argmax(axis=1)
+    assert (np.diff(peaks) >= 0).all() and peaks[0] <= 3 and peaks[-1] >= 480            # triangles ordered from 0 Hz to sr/2
+    # Slaney area normalisation: each triangle integrates (in Hz) to 1  (bin spacing sr/n_fft)
+    area = b.sum(axis=1) * (16000.0 / 1024)
+    assert np.allclose(area[5:], 1.0, atol=0.06)
+
+
+def test_npz_store_sampler_and_dataset_roundtrip(tmp_path):
+    import zs_amd  # noqa: F401
+    from zs_amd import dataloader as D, preprocess as P
+    rng = np.random.RandomState(0)
+    path = str(tmp_path / 'dataset_english.npz')
+    with D.NpzStore(path, 'w') as f:
+        tr, te = f.create_group('train'), f.create_group('test')
+        for spk in ('S015', 'S020', 'V001', 'V002'):
+            for utt in ('0001', '0002', '0003'):
+                T = int(rng.randint(60, 200))
+                tr.create_dataset('%s/%s/lin' % (spk, utt), data=rng.rand(T, 513), dtype=np.float32)
+                tr.create_dataset('%s/%s/mel' % (spk, utt), data=rng.rand(T, 80), dtype=np.float32)
+        te.create_dataset('S015/0009/lin', data=rng.rand(50, 513), dtype=np.float32)
+    s2i = str(tmp_path / 'speaker2id.json')
+    idx = str(tmp_path / 'index.json')
+    P.make_samples(path, idx, s2i, make_object='all', seg_len=64, n_samples=50, dset='train')
+    speaker2id = json.load(open(s2i))
+    assert speaker2id == {'S015': 0, 'S020': 1, 'V001': 2, 'V002': 3}                    # sorted speakers (preprocess.py:207-210)
+    samples = json.load(open(idx))
+    assert len(samples) == 50 and set(samples[0]) == {'speaker', 'i', 't'}
+    store = D.NpzStore(path, 'r')
+    for smp in samples:
+        n = store['train/%s/lin' % smp['i']].shape[0]
+        assert n > 64 and 0 <= smp['t'] <= n - 64 and speaker2id[smp['i'].split('/')[0]] == smp['speaker']
+    P.make_samples(path, str(tmp_path / 'src.json'), s2i, make_object='source', seg_len=64, n_samples=20)
+    assert all(not s['i'].startswith('V00') for s in json.load(open(str(tmp_path / 'src.json'))))
+    P.make_samples(path, str(tmp_path / 'tgt.json'), s2i, make_object='target', seg_len=64, n_samples=20)
+    assert all(s['i'].startswith('V00') for s in json.load(open(str(tmp_path / 'tgt.json'))))
+    ds = D.Dataset(path, idx, dset='train', seg_len=64)
+    c, x = next(D.DataLoader(ds, 8))
+    assert tuple(x.shape) == (8, 64, 513) and x.dtype == torch.float32 and c.dtype == torch.int64
+
+
+@pytest.mark.gpu
+def test_get_spectrograms_vs_oracle():
+    import zs_oracle as O
+    import zs_amd  # noqa: F401
+    from zs_amd import preprocess as P
+    rng = np.random.RandomState(3)
+    wavs = [_tone_wav(rng, n, sil) for n, sil in ((16000, 0), (23456, 3000), (801, 0), (40000, 5000), (9999, 0))]
+    got = P.get_spectrograms_batch(wavs)
+    for w, (mel, mag) in zip(wavs, got):
+        omel, omag = O.get_spectrograms(w)
+        assert mag.shape == omag.shape and mel.shape == omel.shape and mag.dtype == np.float32
+        assert mag.min() >= 1e-8 and mag.max() <= 1.0
+        # normalised scale: 1e-3 = 0.1 dB; the log amplifies the fp32 FFT rounding only where the magnitude is near the 1e-5 floor
+        assert np.abs(mag - omag).max() < 2e-3, np.abs(mag - omag).max()
+        assert np.abs(mel - omel).max() < 2e-3, np.abs(mel - omel).max()
+        assert np.abs(mag - omag).mean() < 5e-5
+
+
+@pytest.mark.gpu
+def test_preprocess_end_to_end(tmp_path):
+    """wav files -> dataset container + index JSONs -> Dataset/DataLoader batch (preprocess.py:26-74, dataloader.py)."""
+    from scipy.io import wavfile
+    import zs_amd  # noqa: F401
+    from zs_amd import dataloader as D, preprocess as P
+    rng = np.random.RandomState(5)
+    dirs = {k: tmp_path / k for k in ('source', 'target', 'test')}
+    for k, d in dirs.items():
+        d.mkdir()
+    for spk in ('S015', 'S020'):
+        for utt in ('0001', '0002'):
+            wavfile.write(str(dirs['source'] / ('%s_%s.wav' % (spk, utt))), 16000, (_tone_wav(rng, 16000 + rng.randint(0, 8000)) * 32767).astype(np.int16))
+    for utt in ('0001', '0002'):
+        wavfile.write(str(dirs['target'] / ('V001_%s.wav' % utt)), 16000, (_tone_wav(rng, 20000) * 32767).astype(np.int16))
+        wavfile.write(str(dirs['target'] / ('V002_%s.wav' % utt)), 16000, (_tone_wav(rng, 3000) * 32767).astype(np.int16))      # short: padded
+    wavfile.write(str(dirs['test'] / 'S015_0099.wav'), 16000, (_tone_wav(rng, 12000) * 32767).astype(np.int16))
+    ds_path = str(tmp_path / 'dataset_english.npz')
+    paths = [str(tmp_path / n) for n in ('index.json', 'index_source.json', 'index_target.json', 'speaker2id.json')]
+    P.preprocess(str(dirs['source']), str(dirs['target']), str(dirs['test']), ds_path, paths[0], paths[1], paths[2], paths[3],
+                 seg_len=64, n_samples=16, dset='train', remake=True)
+    store = D.NpzStore(ds_path, 'r')
+    assert store['train/V002/0001/lin'].shape == (65, 513)                       # <= seg_len frames: zero-padded to seg_len + 1 (preprocess.py:95-100)
+    assert store['test/S015/0099/lin'].shape[1] == 513 and store['test/S015/0099/mel'].shape[1] == 80
+    c, x = next(D.DataLoader(D.Dataset(ds_path, paths[0], dset='train', seg_len=64), 4))
+    assert tuple(x.shape) == (4, 64, 513) and float(x.max()) <= 1.0

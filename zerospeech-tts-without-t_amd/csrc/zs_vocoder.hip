@@ -124,6 +124,54 @@ __global__ __launch_bounds__(NTV) void gl_stft_project_kernel(const ZsGlStft p) 
   }
 }
 
+// preprocess.py:227-258 (get_spectrograms) after the host-side trim: pre-emphasis y[n] - c*y[n-1], librosa.stft(n_fft 1024,
+// hop 200, hann(800) centred in the 1024 frame, center=True reflect padding), |.|, 20*log10(max(1e-5, .)), normalise and
+// clip to [1e-8, 1].  One workgroup per (utterance, frame); amp (optional) keeps the linear magnitudes for the mel product.
+__global__ __launch_bounds__(NTV) void pre_spectrogram_kernel(const ZsPreSpec p) {
+  __shared__ float2 bufA[NFFT];
+  __shared__ float2 bufB[NFFT];
+  __shared__ float2 tw[NFFT / 2];
+  const int tid = threadIdx.x, t = blockIdx.x, u = blockIdx.y;
+  const int L = p.n_samples[u];
+  const int T = 1 + L / HOP;                                        // librosa: 1 + len(y) // hop_length frames
+  if (t >= T || L < 2) return;
+  build_twiddles(tw, tid);
+  const float* w = p.wav + (int64_t)u * p.wav_ld;
+  for (int n = tid; n < NFFT; n += NTV) {
+    int idx = t * HOP + n - NFFT / 2;                               // np.pad(y, 512, mode='reflect') of the pre-emphasised signal
+    if (idx < 0) idx = -idx;
+    if (idx >= L) idx = 2 * (L - 1) - idx;
+    idx = min(max(idx, 0), L - 1);
+    const float y = idx > 0 ? w[idx] - p.preemph * w[idx - 1] : w[0];
+    bufA[n] = make_float2(y * hann_padded(n), 0.f);
+  }
+  __syncthreads();
+  const float2* E = fft1024(bufA, bufB, tw, tid, -1.0f);
+  float* out = p.mag + ((int64_t)u * p.T_max + t) * p.mag_ld;
+  float* amp = p.amp ? p.amp + ((int64_t)u * p.T_max + t) * NBIN : nullptr;
+  for (int k = tid; k < NBIN; k += NTV) {
+    const float2 e = E[k];
+    const float a = sqrtf(e.x * e.x + e.y * e.y);
+    if (amp) amp[k] = a;
+    const float db = 20.f * log10f(fmaxf(1e-5f, a));
+    out[k] = fminf(fmaxf((db - p.ref_db + p.max_db) / p.max_db, 1e-8f), 1.f);
+  }
+}
+
+// mel[t][m] = clip((20 log10(max(1e-5, sum_k basis[m][k] amp[t][k])) - ref + max) / max, 1e-8, 1)   (preprocess.py:243-252)
+__global__ void pre_mel_kernel(const float* amp, const float* basis, float* mel, int64_t rows, int n_mels, float ref_db, float max_db) {
+  const int64_t r = blockIdx.x;
+  if (r >= rows) return;
+  for (int m = threadIdx.x; m < n_mels; m += blockDim.x) {
+    const float* a = amp + r * NBIN;
+    const float* b = basis + (int64_t)m * NBIN;
+    float s = 0.f;
+    for (int k = 0; k < NBIN; ++k) s += b[k] * a[k];
+    const float db = 20.f * log10f(fmaxf(1e-5f, s));
+    mel[r * n_mels + m] = fminf(fmaxf((db - ref_db + max_db) / max_db, 1e-8f), 1.f);
+  }
+}
+
 __global__ void gl_denorm_kernel(const float* in, float* out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float m = fminf(fmaxf(in[i], 0.f), 1.f) * 100.f - 100.f + 20.f;   // convert.py:57
@@ -157,6 +205,21 @@ extern "C" int zs_gl_stft_project(const ZsGlStft* p, void* stream) {
   ZS_REQUIRE(p && p->wav && p->mag && p->lengths && p->spec && p->n_utt > 0 && p->T_max > 1, "zs_gl_stft_project: bad args");
   hipLaunchKernelGGL(gl_stft_project_kernel, dim3(p->T_max, p->n_utt), dim3(NTV), 0, (hipStream_t)stream, *p);
   return zs_check_launch("zs_gl_stft_project");
+}
+
+extern "C" int zs_pre_spectrogram(const ZsPreSpec* p, void* stream) {
+  ZS_REQUIRE(p && p->wav && p->n_samples && p->mag && p->n_utt > 0 && p->T_max > 0 && p->mag_ld >= NBIN && p->max_db > 0.f,
+             "zs_pre_spectrogram: bad args");
+  hipLaunchKernelGGL(pre_spectrogram_kernel, dim3(p->T_max, p->n_utt), dim3(NTV), 0, (hipStream_t)stream, *p);
+  return zs_check_launch("zs_pre_spectrogram");
+}
+
+extern "C" int zs_pre_mel(const float* amp, const float* basis, float* mel, int64_t rows, int32_t n_mels, float ref_db, float max_db,
+                          void* stream) {
+  ZS_REQUIRE(amp && basis && mel && rows > 0 && n_mels > 0 && max_db > 0.f, "zs_pre_mel: bad args");
+  ZS_REQUIRE(rows < (1ll << 31), "zs_pre_mel: too many rows");
+  hipLaunchKernelGGL(pre_mel_kernel, dim3((unsigned)rows), dim3(128), 0, (hipStream_t)stream, amp, basis, mel, rows, (int)n_mels, ref_db, max_db);
+  return zs_check_launch("zs_pre_mel");
 }
 
 extern "C" int zs_gl_denormalize(const float* mag_norm, float* mag_amp, int64_t n, void* stream) {

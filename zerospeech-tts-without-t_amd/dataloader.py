@@ -81,15 +81,60 @@ class DevicePrefetcher(object):
         return sl[2], sl[3]
 
 
-class Dataset(torch.utils.data.Dataset):
-    """HDF5-backed segments, dataloader.py:56-78 (layout `{dset}/{speaker}/{utt}/lin|mel`)."""
+class NpzStore(object):
+    """h5py-shaped container on an .npz file: `create_group(name)`, `group.create_dataset(key, data=, dtype=)`, `store[key]`."""
 
-    def __init__(self, h5_path, index_path, dset='train', seg_len=64, load_mel=False):
+    class _Group(object):
+        def __init__(self, store, prefix):
+            self.store, self.prefix = store, prefix
+
+        def create_dataset(self, key, data, dtype=np.float32):
+            self.store.arrays[self.prefix + '/' + key] = np.asarray(data, dtype=dtype)
+
+    def __init__(self, path, mode='r'):
+        self.path, self.mode, self.arrays = path, mode, {}
+        if mode == 'r':
+            with np.load(path, allow_pickle=False) as z:
+                self.arrays = {k: z[k] for k in z.files}
+
+    def create_group(self, name):
+        return NpzStore._Group(self, name)
+
+    def __getitem__(self, key):
+        return self.arrays[key]
+
+    def keys(self, prefix):
+        """Names directly under `prefix` (h5py: list(f[prefix].keys()))."""
+        p = prefix.rstrip('/') + '/'
+        return sorted({k[len(p):].split('/')[0] for k in self.arrays if k.startswith(p)})
+
+    def close(self):
+        if self.mode == 'w':
+            np.savez(self.path, **self.arrays)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def open_store(path, mode='r'):
+    """HDF5 (h5py) when available and the path is not .npz; the NpzStore otherwise."""
+    if not path.endswith('.npz'):
         try:
             import h5py
-        except ImportError as e:                         # not installed in the build image
-            raise ImportError('zs_amd.dataloader.Dataset needs h5py to read %s' % h5_path) from e
-        self.dataset = h5py.File(h5_path, 'r')
+            return h5py.File(path, mode)
+        except ImportError:
+            path = path + '.npz'
+    return NpzStore(path, mode)
+
+
+class Dataset(torch.utils.data.Dataset):
+    """HDF5- (or .npz-) backed segments, dataloader.py:56-78 (layout `{dset}/{speaker}/{utt}/lin|mel`)."""
+
+    def __init__(self, h5_path, index_path, dset='train', seg_len=64, load_mel=False):
+        self.dataset = open_store(h5_path, 'r')         # HDF5 (h5py) or the .npz container written by zs_amd.preprocess
         with open(index_path) as f_index:
             self.indexes = json.load(f_index)
         self.indexer = namedtuple('index', ['speaker', 'i', 't'])
