@@ -389,6 +389,54 @@ def _gru_case(L, layers, dtype, shape):
         _close('gru grad ' + k, Gd[k], Pr[k].grad, tol)
 
 
+def test_gru_full_size_persistent_equals_stepwise_and_is_deterministic(zs):
+    """Decoder GRU at the bench size (B=256, T=128, H=512, bf16): the persistent kernels (granule hand-off between 256
+    workgroups) against the one-launch-per-step path, and two persistent runs against each other bit for bit -- a race in the
+    hand-off would show up here as a difference."""
+    L, layers = zs
+    B, T, Cin, H = 256, 128, 1024, 512
+    ctx = _ctx(layers, 'bf16')
+    dev = ctx.device
+    g = torch.Generator().manual_seed(21)
+    P = {}
+    for sfx in ('', '_reverse'):
+        P['RNN.weight_ih_l0' + sfx] = torch.randn(3 * H, Cin, generator=g) / math.sqrt(Cin)
+        P['RNN.weight_hh_l0' + sfx] = torch.randn(3 * H, H, generator=g) / math.sqrt(H)
+        P['RNN.bias_ih_l0' + sfx] = torch.randn(3 * H, generator=g) * 0.1
+        P['RNN.bias_hh_l0' + sfx] = torch.randn(3 * H, generator=g) * 0.1
+    Pd = {k: v.to(dev).contiguous() for k, v in P.items()}
+    Gd = {k: torch.zeros_like(v) for k, v in Pd.items()}
+    gru = layers.GruLayer(ctx, Pd, Gd, 'RNN.', name='full')
+    gru.pack()
+    X = ctx.act('fx', B, T, Cin)
+    X.t[:B * T * X.ld].copy_(torch.randn(B * T * X.ld, generator=g).to(dev))
+    dcat = ctx.act('fdcat', B, T, Cin + 2 * H)
+    dcat.t[:B * T * dcat.ld].copy_((torch.randn(B * T * dcat.ld, generator=g) * 0.1).to(dev))
+    res = {}
+    for tag, persist in (('p1', 1), ('p2', 1), ('step', 0)):
+        old = L.set_option('gru_persist', persist)
+        try:
+            cat = ctx.act('fcat' + tag, B, T, Cin + 2 * H)
+            gi = ctx.act('fgi' + tag, B, T, 6 * H)
+            gates = ctx.raw('fgates' + tag, B * T * 8 * H, ctx.tdt)
+            dgi, dgh = ctx.act('fdgi' + tag, B, T, 6 * H), ctx.act('fdgh' + tag, B, T, 6 * H)
+            dX = ctx.act('fdX' + tag, B, T, Cin)
+            gru.fwd(X, cat, Cin, gi, gates)
+            gru.check(B)
+            gru.bwd(dcat, Cin, cat, Cin, gates, X, dgi, dgh, dX)
+            gru.check(B)
+            torch.cuda.synchronize()
+            res[tag] = (cat.valid()[:, :, Cin:].float().clone(), dX.valid().float().clone(), dgh.valid().float().clone(),
+                        Gd['RNN.weight_hh_l0'].clone())
+        finally:
+            L.set_option('gru_persist', old)
+    for a, b in zip(res['p1'], res['p2']):
+        assert torch.equal(a, b), 'persistent GRU is not deterministic'
+    for name, a, b in zip(('h', 'dX', 'dgh', 'dW_hh'), res['p1'], res['step']):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-2 * scale, (name, float((a - b).abs().max()), scale)
+
+
 def test_loss_norm_adam(zs):
     L, layers = zs
     torch.manual_seed(1)
