@@ -267,6 +267,8 @@ def main():
     if rank == 0 and not args.no_kernel_events:
         isolated = isolated_kernel_rate(dev, args.dtype)
     loss = float(ae._loss.item())
+    for net in (enc, dec):                             # the persistent GRU kernels give up (bounded spins) instead of hanging: make sure none did
+        net._engine().gru.check(B)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
