@@ -116,3 +116,14 @@ def test_preprocess_end_to_end(tmp_path):
     assert store['test/S015/0099/lin'].shape[1] == 513 and store['test/S015/0099/mel'].shape[1] == 80
     c, x = next(D.DataLoader(D.Dataset(ds_path, paths[0], dset='train', seg_len=64), 4))
     assert tuple(x.shape) == (4, 64, 513) and float(x.max()) <= 1.0
+    # ... and --test_encode (convert.py:342-360) reads the same container: one encodings .txt per test wav
+    from zs_amd import convert as cv
+    from zs_amd.hps import make_hps
+    from zs_amd.trainer import Trainer
+    hps = make_hps(enc_size=16, emb_size=32, n_speakers=4, seg_len=64)
+    tr = Trainer(hps, None, 'targeted_residual', 'multilabel_binary', log_dir=str(tmp_path / 'log'), dtype='fp32')
+    cv.test_encode(tr, 64, str(dirs['test']), ds_path, str(tmp_path / 'result'), flag='test')
+    outs = os.listdir(str(tmp_path / 'result' / 'test'))
+    assert len(outs) == 1 and outs[0].endswith('.txt')
+    rows = open(str(tmp_path / 'result' / 'test' / outs[0])).read().strip().split('\n')
+    assert all(set(r.split(' ')) <= {'0', '1'} and len(r.split(' ')) == 16 for r in rows)

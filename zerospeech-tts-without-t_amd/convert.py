@@ -282,11 +282,9 @@ def write_wav(path, wav, sr):
 
 
 def _open_h5(path):
-    try:
-        import h5py
-    except ImportError as e:
-        raise ImportError('reading %s needs h5py' % path) from e
-    return h5py.File(path, 'r')
+    """The preprocessed dataset: HDF5 when h5py is importable, else the .npz container zs_amd.preprocess writes."""
+    from .dataloader import open_store
+    return open_store(path, 'r')
 
 
 def test_from_list(trainer, seg_len, synthesis_list, data_path, speaker2id_path, result_dir, enc_only, flag='test', run_asr=False):
