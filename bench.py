@@ -1,7 +1,9 @@
 """bench.py -- throughput of the --train_ae step (BASELINE.json metric) on N MI355X GPUs.
 
   python bench.py --gpus N --steps K --warmup W [--dtype bf16|fp32] [--batch 256] [--no-cpu-baseline]
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+  N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK / WORLD_SIZE in
+  the environment), or plainly as `python bench.py --gpus N`: the parent then starts N rank processes itself (before it makes
+  any GPU call) and returns rank 0's JSON line.  A world size that differs from --gpus is an error, never a silent 1-rank run.
 
 A "step" is one pass of the hot path over one batch of synthetic segments resident in HBM: Encoder fwd,
 Decoder fwd, L1, full backward, per-net clip, Adam (dropout and Gumbel noise ON, nothing skipped).
@@ -173,8 +175,36 @@ class KernelEvents(object):
         return tot_fl, tot_ms, len(self.pairs)
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without torchrun: start N rank processes (one per GPU) with the torchrun environment
+    contract.  The parent has made no GPU call (importing torch does not initialise HIP) and only waits; rank 0's stdout is
+    the parent's, so the single JSON line comes out unchanged.  Returns the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        env.setdefault('OMP_NUM_THREADS', str(max(1, cpu_share() // args.gpus)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=(None if r == 0 else subprocess.DEVNULL)))
+    rc = 0
+    for r, pr in enumerate(procs):
+        code = pr.wait()
+        if code != 0:
+            log('rank %d exited with code %d' % (r, code))
+            rc = rc or code
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))
     import zs_amd  # noqa: F401
     from zs_amd import parallel
     from zs_amd.model import Decoder, Encoder
@@ -187,7 +217,10 @@ def main():
     if force_dev is not None:
         torch.cuda.set_device(int(force_dev))
     rank, world, local = parallel.init_from_env(os.environ.get('ZS_DIST_BACKEND', 'nccl'))
-    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    if world != args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE is %d: refusing to report a %d-GPU number from %d rank(s)\n' %
+                         (args.gpus, world, args.gpus, world))
+        sys.exit(2)
     dev = torch.device('cuda', int(force_dev) if force_dev is not None else local)
     torch.cuda.set_device(dev)
     seg_len, F, E, ch, nspk, B = 128, 513, 1024, 1024, 102, args.batch
@@ -267,8 +300,8 @@ def main():
     if rank == 0 and not args.no_kernel_events:
         isolated = isolated_kernel_rate(dev, args.dtype)
     loss = float(ae._loss.item())
-    for net in (enc, dec):                             # the persistent GRU kernels give up (bounded spins) instead of hanging: make sure none did
-        net._engine().gru.check(B)
+    from zs_amd import layers
+    layers.check_status(dev)                           # sticky status word: raises if ANY persistent GRU pass of this run timed out
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -286,7 +319,7 @@ def main():
         'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': 'train_ae english hps seg_len=128 enc_size=1024 emb_size=1024 n_speakers=102 F=513, batch=%d/GPU, '
                                'dropout+Gumbel on, fwd+bwd+clip+Adam' % B, 'global_batch': B * world, 'parallelism': 'dp%d' % world},
-        'final_loss': loss, 'host_input': bool(args.host_input), 'host_enqueue_ms_per_step': 1e3 * t_host / args.steps, 'hipgraph': bool(ae.use_graph and (world == 1 or os.environ.get('ZS_GRAPH_MULTI', '0') == '1')),
+        'final_loss': loss, 'host_input': bool(args.host_input), 'host_enqueue_ms_per_step': 1e3 * t_host / args.steps, 'hipgraph': bool(ae.use_graph and (world == 1 or os.environ.get('ZS_GRAPH_MULTI', '1') == '1')),
     }
     peak = 2500.0 if args.dtype == 'bf16' else 157.3
     traffic = None
@@ -311,7 +344,10 @@ def main():
         out['roofline']['isolated'] = isolated
     out['step_tflops'] = 180.7e6 * value / 1e12          # 180.7 MFLOP per frame for the whole step
     if world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(seg_len, F, E, ch, nspk)
+        out['cpu_baseline'] = cpu_baseline(seg_len, F, E, ch, nspk)                    # the reference's own batch size
+        if B != 16:
+            big = cpu_baseline(seg_len, F, E, ch, nspk, steps=2, batch=B)              # and the GPU configuration's
+            out['cpu_baseline']['at_gpu_batch'] = {k: big[k] for k in ('value', 'unit', 'sample')}
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

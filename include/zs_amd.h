@@ -50,6 +50,9 @@ const char* zs_last_error(void);
  *   "gru_persist" (ZS_GRU_PERSIST, 1): one persistent launch per GRU pass (forward and BPTT: the time loop runs on the
  *       device, W_hh stays in registers, h / dgh travel between workgroups as data-tagged 8-byte granules) when the grid fits
  *       one workgroup per CU and H allows it; 0 = one launch per time step
+ *   "gru_spin_limit" (ZS_GRU_SPIN_LIMIT, 2^21): granule sweeps a persistent GRU wave makes before it gives up on its group
+ *       (sets the status word, see ZsGruFwd.status); 0 forces the timeout path (tests)
+ * The knobs are process-wide atomics: they may be set from any thread; a launch reads each knob once.
  * Returns the previous value, or ZS_EINVAL for an unknown key. */
 int zs_set_option(const char* key, int value);
 
@@ -271,6 +274,10 @@ typedef struct {
   void* gates; /* T dtype [B][T][2][4H] or null (inference) */
   float* work; size_t work_bytes;   /* >= zs_gru_work_bytes */
   int32_t whh_interleaved;
+  uint32_t* status;              /* optional caller-owned device word, STICKY: a persistent pass whose bounded spin expires ORs
+                                    bit 0 (forward) / bit 1 (BPTT) into it and goes on with invalid data; the library never
+                                    clears it.  The caller reads it at its own host sync points (Trainer.train: every logged
+                                    loss; convert/encode: the end of a batch) and raises. */
 } ZsGruFwd;
 size_t zs_gru_work_bytes(int32_t B, int32_t H);
 int zs_gru_fwd(const ZsGruFwd* p, void* stream);
@@ -287,6 +294,7 @@ typedef struct {
   void* dgi; int64_t ldgi;       /* [B*T][ldgi] cols dir*3H.. : grad w.r.t. gi (input projections) */
   void* dgh; int64_t ldgh;       /* same shape: grad w.r.t. (h W_hh^T + b_hh) */
   float* work; size_t work_bytes;
+  uint32_t* status;              /* sticky status word, see ZsGruFwd */
 } ZsGruBwd;
 int zs_gru_bwd(const ZsGruBwd* p, void* stream);
 
@@ -311,12 +319,15 @@ int zs_sqnorm(const float* g, int64_t n, double* partial, float* out_sq, void* s
 /* zs_adam_clip: nn.utils.clip_grad_norm_(max_norm) (utils.py:53-55) fused with torch.optim.Adam's
  * single-tensor update (trainer.py:66,332): coef = min(1, max_norm/(sqrt(sumsq)+1e-6)); g *= coef;
  * m = m + (g-m)(1-b1); v = v*b2 + g*g*(1-b2); p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps).
- * sumsq is a device scalar (from zs_sqnorm); max_norm <= 0 disables clipping. */
+ * sumsq is a device scalar (from zs_sqnorm); max_norm <= 0 disables clipping.
+ * grad_scale (0 = 1): g holds grad_scale^-1 times the gradient -- the SUM over `world` data-parallel ranks with
+ * grad_scale = 1/world -- so the average is never materialised: norm = grad_scale*sqrt(sumsq), g_eff = g*grad_scale*coef. */
 typedef struct {
   float* p; float* g; float* m; float* v; int64_t n;
   float lr, beta1, beta2, eps, bc1, bc2;
   const float* sumsq; float max_norm; int32_t write_clipped_grad;
   const int32_t* step_ptr;       /* optional device step count t: bc1 = 1-beta1^t, bc2 = 1-beta2^t computed on device */
+  float grad_scale;
 } ZsAdam;
 int zs_adam_clip(const ZsAdam* p, void* stream);
 

@@ -94,11 +94,10 @@ def main(argv=None):
     if args.train or args.train_ae:
         rank, world, _ = parallel.init_from_env()
         if args.synthetic:
-            dataset = SyntheticDataset(max(4 * hps.batch_size, 64), seg_len=hps.seg_len, n_speakers=hps.n_speakers, rank=rank)
+            dataset = SyntheticDataset(max(4 * hps.batch_size * world, 64), seg_len=hps.seg_len, n_speakers=hps.n_speakers)
         else:
             dataset = Dataset(args.dataset_path, args.index_path, seg_len=hps.seg_len)
-        data_loader = DataLoader(dataset, hps.batch_size)
-        data_loader.index = (rank * hps.batch_size) % max(1, len(dataset) - 2 * hps.batch_size)   # rank-offset into the index
+        data_loader = DataLoader(dataset, hps.batch_size, rank=rank, world=world)      # disjoint per-rank shards of each global batch
         os.makedirs(args.ckpt_dir, exist_ok=True)
         model_path = os.path.join(args.ckpt_dir, args.model_name)
         trainer = Trainer(hps, data_loader, args.g_mode, args.enc_mode, dtype=args.dtype)

@@ -179,6 +179,8 @@ def _dp_worker(rank, world, port, q):
     red = parallel.GradReducer(bucket_bytes=64 << 10)          # several buckets
     red.start(flat)
     red.finish()
+    assert red.scale == 0.5
+    flat = flat * red.scale            # the buffers hold the SUM over ranks; the consumer (zs_adam_clip) folds 1/world in
     if rank == 0:
         _, (fe, fd), _, _ = O.train_ae_grads(sub_sd(d, 'enc0.'), sub_sd(d, 'dec0.'), x, c, hp, G=G)
         full = torch.cat([v.reshape(-1) for v in list(fe.values()) + list(fd.values())])
@@ -202,6 +204,58 @@ def test_data_parallel_gradient_average_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert world == 2 and err <= 2e-5 * scale, (err, scale)
+
+
+def test_data_parallel_loader_shards_are_disjoint():
+    """world 2: rank r serves items [index + r*B, index + (r+1)*B) of each global batch and both advance by world*B -- no item
+    is served twice before the wrap; world 1 is the reference's sequence (dataloader.py:43-52)."""
+    from zs_amd.dataloader import DataLoader
+
+    class Ids(object):
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+        def __getitem__(self, i):
+            assert 0 <= i < self.n
+            return (np.int64(i), np.full((2, 3), i, dtype=np.float32))
+
+    B, n = 4, 100
+    loaders = [DataLoader(Ids(n), B, rank=r, world=2) for r in range(2)]
+    seen = []
+    for step in range(11):                      # 11 global batches of 8 = 88 items: 88 + 16 >= 100 wraps after the 11th
+        assert loaders[0].index == loaders[1].index == step * 8
+        for dl in loaders:
+            seen += next(dl)[0].tolist()
+    assert len(seen) == len(set(seen)) == 88 and sorted(seen) == list(range(88))
+    next(loaders[0]); next(loaders[1])
+    assert loaders[0].index == loaders[1].index == 0          # wrapped together
+    single = DataLoader(Ids(n), B)
+    ref = []
+    for _ in range(5):
+        ref += next(single)[0].tolist()
+    assert ref == list(range(20))
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """`bench.py --gpus 2` under a 1-rank environment must be an error, not a 1-GPU number labelled n_gpus 2."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and 'refusing' in r.stderr and r.stdout.strip() == ''
+
+
+def test_sanitizer_build_command():
+    """ZS_SANITIZE=address: host-side instrumentation only (each -fsanitize= directly after -Xarch_host), separate output."""
+    from zs_amd import build as zb
+    cmd = zb.command(san='address')
+    i = cmd.index('-fsanitize=address')
+    assert cmd[i - 1] == '-Xarch_host' and cmd[cmd.index('-o') + 1].endswith('libzs_amd.address.so')
+    assert '--offload-arch=gfx950' in cmd
+    assert zb.command(san='')[zb.command(san='').index('-o') + 1].endswith('libzs_amd.so')
 
 
 def test_shard_range():

@@ -1,4 +1,9 @@
-"""In-tree build of libzs_amd.so: hipcc cross-compiles the gfx950 code objects without a GPU."""
+"""In-tree build of libzs_amd.so: hipcc cross-compiles the gfx950 code objects without a GPU.
+
+ZS_SANITIZE=address|undefined builds a second library, libzs_amd.<san>.so, whose HOST code (argument checks, plans,
+launch logic, the C-ABI entry points) is instrumented; the device code objects are unchanged (GPU sanitizers are not
+available on this pool).  zs_amd._lib loads that variant when ZS_SANITIZE is set in its environment; run the
+interpreter with the matching runtime preloaded, e.g. LD_PRELOAD=$(hipcc -print-file-name=libclang_rt.asan-x86_64.so)."""
 import glob
 import os
 import subprocess
@@ -6,31 +11,56 @@ import sys
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_PKG, 'csrc')
-OUT = os.path.join(_PKG, 'libzs_amd.so')
+
+
+def sanitize():
+    s = os.environ.get('ZS_SANITIZE', '').strip()
+    if s and s not in ('address', 'undefined'):
+        raise ValueError('ZS_SANITIZE must be address or undefined (got %r)' % s)
+    return s
+
+
+def out_path(san=None):
+    san = sanitize() if san is None else san
+    return os.path.join(_PKG, 'libzs_amd.%s.so' % san if san else 'libzs_amd.so')
+
+
+OUT = out_path('')
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
 
 
-def needs_build():
-    if not os.path.exists(OUT):
+def needs_build(out=None):
+    out = out or out_path()
+    if not os.path.exists(out):
         return True
-    t = os.path.getmtime(OUT)
+    t = os.path.getmtime(out)
     deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + [os.path.join(os.path.dirname(_PKG), 'include', 'zs_amd.h')]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    if not force and not needs_build():
-        return OUT
+def command(out=None, san=None):
+    san = sanitize() if san is None else san
+    out = out or out_path(san)
     hipcc = os.environ.get('HIPCC', 'hipcc')
-    cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared', '-Wno-unused-result',
-           '-o', OUT] + sources()
+    cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared', '-Wno-unused-result']
+    if san:
+        # host side only: each -fsanitize= directly after -Xarch_host
+        cmd += ['-Xarch_host', '-fsanitize=%s' % san, '-Xarch_host', '-fno-omit-frame-pointer', '-g', '-shared-libsan']
+    return cmd + ['-o', out] + sources()
+
+
+def build(force=False, verbose=True):
+    out = out_path()
+    if not force and not needs_build(out):
+        return out
+    cmd = command(out)
     if verbose:
         print('[zs_amd.build]', ' '.join(cmd))
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == '__main__':

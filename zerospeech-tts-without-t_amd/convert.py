@@ -261,6 +261,8 @@ def encode_batch(specs, trainer, seg_len, decode_speakers=None, noise_fn=None, m
             enc_out[(u, k)] = e[i][:trunc] if trunc is not None else e[i]
             if xd is not None:
                 dec_out[(u, k)] = xd[i]
+    from . import layers
+    layers.check_status(dev)                                  # the .cpu() copies synchronised: a timed-out GRU pass raises here
     encs, decs = [], ([] if decode_speakers is not None else None)
     for u in range(len(specs)):
         ks = sorted(k for (uu, k) in enc_out if uu == u)

@@ -201,10 +201,11 @@ __global__ void sqnorm_stage2_kernel(const double* partial, int n, float* out) {
 
 // ---- Adam + clip -------------------------------------------------------------------------------------
 __global__ void adam_kernel(const ZsAdam p) {
-  float coef = 1.f;
+  const float gs = p.grad_scale != 0.f ? p.grad_scale : 1.f;      // 1/world: g holds the SUM over the data-parallel ranks
+  float coef = gs;
   if (p.max_norm > 0.f && p.sumsq) {
-    const float norm = sqrtf(*p.sumsq);
-    coef = fminf(p.max_norm / (norm + 1e-6f), 1.f);              // clip_grad_norm_
+    const float norm = sqrtf(*p.sumsq) * gs;
+    coef = gs * fminf(p.max_norm / (norm + 1e-6f), 1.f);         // clip_grad_norm_
   }
   float bc1 = p.bc1, bc2 = p.bc2;
   if (p.step_ptr) {                                              // hipGraph replay: the step count lives on the device

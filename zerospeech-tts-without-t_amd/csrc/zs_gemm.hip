@@ -22,6 +22,9 @@
 //  * blockIdx -> tile maps are XCD-aware (tiles that share operand panels get the same XCD's L2).
 #include <stdlib.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "zs_common.h"
 
 namespace {
@@ -1772,7 +1775,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ZsGemmWgrad p, 
 }
 
 int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-int g_wgrad_p8 = -1;
+// Kernel-selection knobs: process-wide relaxed atomics (settable from any thread; every launch reads each knob once into a
+// local).  Defaults come from the environment on first use.
+struct Knob {
+  std::atomic<int> v{-1};
+  const char* env; int dflt;
+  Knob(const char* e, int d) : env(e), dflt(d) {}
+  int get() {
+    int x = v.load(std::memory_order_relaxed);
+    if (x < 0) { x = env_int(env, dflt); if (x < 0) x = 0; v.store(x, std::memory_order_relaxed); }
+    return x;
+  }
+  int set(int nv) { const int old = get(); v.store(nv < 0 ? 0 : nv, std::memory_order_relaxed); return old; }
+};
+Knob g_wgrad_p8("ZS_WGRAD_P8", 1);
 
 struct WgradPlan { int p8, splits, tile, co_tiles, ci_tiles, cout_r, cin_r, rows_per_split; };
 
@@ -1781,13 +1797,13 @@ struct WgradPlan { int p8, splits, tile, co_tiles, ci_tiles, cout_r, cin_r, rows
 // rounds x (K tiles per split + 13).
 WgradPlan wgrad_plan(const ZsGemmWgrad* p) {
   WgradPlan w;
-  if (g_wgrad_p8 < 0) g_wgrad_p8 = env_int("ZS_WGRAD_P8", 1);
+  const int wgrad_p8 = g_wgrad_p8.get();
   const int64_t M = (int64_t)p->B * p->T_out;
   const int64_t t256 = (int64_t)((p->Cout + 255) / 256) * p->taps * ((p->Cin + 255) / 256);
   // padding waste of 256-wide tiles must stay small, and there must be enough K per workgroup to amortise the slab
   const double waste = (double)(((p->Cout + 255) / 256) * 256) * (((p->Cin + 255) / 256) * 256) / ((double)p->Cout * p->Cin);
-  w.p8 = g_wgrad_p8 && p->dtype == ZS_BF16 && waste <= 1.35 && M >= 2048 && (g_wgrad_p8 > 1 || t256 * M >= (int64_t)16 * 8192);
-  if (g_wgrad_p8 > 1 && p->dtype == ZS_BF16) w.p8 = 1;                 // forced (tests)
+  w.p8 = wgrad_p8 && p->dtype == ZS_BF16 && waste <= 1.35 && M >= 2048 && (wgrad_p8 > 1 || t256 * M >= (int64_t)16 * 8192);
+  if (wgrad_p8 > 1 && p->dtype == ZS_BF16) w.p8 = 1;                   // forced (tests)
   w.tile = w.p8 ? 256 : 128;
   w.co_tiles = (p->Cout + w.tile - 1) / w.tile; w.ci_tiles = (p->Cin + w.tile - 1) / w.tile;
   w.cout_r = w.co_tiles * w.tile; w.cin_r = w.ci_tiles * w.tile;
@@ -1819,14 +1835,19 @@ WgradPlan wgrad_plan(const ZsGemmWgrad* p) {
 
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-int g_use_dma = -1, g_use_ring = -1, g_ring_min_tiles = -1, g_use_pp = -1, g_use_p8 = -1, g_p8_min_tiles = -1;
-void init_options() {
-  if (g_use_dma < 0) g_use_dma = env_int("ZS_GEMM_DMA", 1);
-  if (g_use_ring < 0) g_use_ring = env_int("ZS_GEMM_RING", 1);
-  if (g_ring_min_tiles < 0) g_ring_min_tiles = env_int("ZS_GEMM_RING_MIN_TILES", 256);
-  if (g_use_pp < 0) g_use_pp = env_int("ZS_GEMM_PP", 1);
-  if (g_use_p8 < 0) g_use_p8 = env_int("ZS_GEMM_P8", 2);
-  if (g_p8_min_tiles < 0) g_p8_min_tiles = env_int("ZS_GEMM_P8_MIN_TILES", 200);
+Knob g_use_dma("ZS_GEMM_DMA", 1), g_use_ring("ZS_GEMM_RING", 1), g_ring_min_tiles("ZS_GEMM_RING_MIN_TILES", 256), g_use_pp("ZS_GEMM_PP", 1),
+    g_use_p8("ZS_GEMM_P8", 2), g_p8_min_tiles("ZS_GEMM_P8_MIN_TILES", 200);
+
+// one-time raise of the dynamic-LDS limit of the big-tile kernels (std::call_once: launches may come from several threads)
+std::once_flag g_lds_attr_once;
+void set_lds_attrs() {
+  const void* big[] = {reinterpret_cast<const void*>(gemm_conv_p8_kernel<float>), reinterpret_cast<const void*>(gemm_conv_p8_kernel<bf16_t>),
+                       reinterpret_cast<const void*>(gemm_conv_p8m16_kernel<float>), reinterpret_cast<const void*>(gemm_conv_p8m16_kernel<bf16_t>),
+                       reinterpret_cast<const void*>(gemm_wgrad_p8_kernel)};
+  for (const void* f : big) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+  const void* ring[] = {reinterpret_cast<const void*>(gemm_conv_ring_kernel<float, 0>), reinterpret_cast<const void*>(gemm_conv_ring_kernel<bf16_t, 0>),
+                        reinterpret_cast<const void*>(gemm_conv_ring_kernel<float, 1>), reinterpret_cast<const void*>(gemm_conv_ring_kernel<bf16_t, 1>)};
+  for (const void* f : ring) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);
 }
 
 }  // namespace
@@ -1862,42 +1883,22 @@ extern "C" int zs_gemm_conv(const ZsGemmConv* p, void* stream) {
   ZS_REQUIRE(tiles < (1ll << 31), "zs_gemm_conv: grid too large");
   dim3 grid((unsigned)tiles, 1, (unsigned)groups);
   hipStream_t s = (hipStream_t)stream;
-  init_options();
-  const int use_dma = g_use_dma, use_ring = g_use_ring;
+  std::call_once(g_lds_attr_once, set_lds_attrs);
+  const int use_dma = g_use_dma.get(), use_ring = g_use_ring.get(), use_p8 = g_use_p8.get(), use_pp = g_use_pp.get();
   const int64_t ring_tiles = ((M + RBM - 1) / RBM) * ((p->N + BN - 1) / BN);
   const int64_t p8_tiles = ((M + PBM - 1) / PBM) * ((p->N + PBN - 1) / PBN);
-  if (use_dma && g_use_p8 && p->n_pad % PBN == 0 && p8_tiles >= g_p8_min_tiles && p8_tiles < (1ll << 31)) {
+  if (use_dma && use_p8 && p->n_pad % PBN == 0 && p8_tiles >= g_p8_min_tiles.get() && p8_tiles < (1ll << 31)) {
     // enough 256x256 tiles for most of the chip: quadrant ping-pong kernel
     dim3 pgrid((unsigned)p8_tiles, 1, (unsigned)groups);
-    static bool p8_attr = false;
-    if (!p8_attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_p8_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_p8_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
-      p8_attr = true;
-    }
-    if (g_use_p8 == 2) {
-      static bool m16_attr = false;
-      if (!m16_attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_p8m16_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_p8m16_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
-        m16_attr = true;
-      }
+    if (use_p8 == 2) {
       if (p->dtype == ZS_F32) hipLaunchKernelGGL(gemm_conv_p8m16_kernel<float>, pgrid, dim3(PNT), P8_LDS, s, *p);
       else hipLaunchKernelGGL(gemm_conv_p8m16_kernel<bf16_t>, pgrid, dim3(PNT), P8_LDS, s, *p);
     } else if (p->dtype == ZS_F32) hipLaunchKernelGGL(gemm_conv_p8_kernel<float>, pgrid, dim3(PNT), P8_LDS, s, *p);
     else hipLaunchKernelGGL(gemm_conv_p8_kernel<bf16_t>, pgrid, dim3(PNT), P8_LDS, s, *p);
-  } else if (use_dma && use_ring && ring_tiles >= g_ring_min_tiles && ring_tiles < (1ll << 31)) {
+  } else if (use_dma && use_ring && ring_tiles >= g_ring_min_tiles.get() && ring_tiles < (1ll << 31)) {
     // enough 256x128 tiles to give every CU one workgroup: 3-stage ring kernel
     dim3 rgrid((unsigned)ring_tiles, 1, (unsigned)groups);
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_ring_kernel<float, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_ring_kernel<bf16_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_ring_kernel<float, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_ring_kernel<bf16_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);
-      attr_set = true;
-    }
-    if (g_use_pp) {
+    if (use_pp) {
       if (p->dtype == ZS_F32) hipLaunchKernelGGL((gemm_conv_ring_kernel<float, 1>), rgrid, dim3(RNT), RING_LDS, s, *p);
       else hipLaunchKernelGGL((gemm_conv_ring_kernel<bf16_t, 1>), rgrid, dim3(RNT), RING_LDS, s, *p);
     } else {
@@ -1917,20 +1918,18 @@ extern "C" int zs_gemm_conv(const ZsGemmConv* p, void* stream) {
 }
 
 extern "C" int zs_set_option(const char* key, int value) {
-  init_options();
-  int* slot = nullptr;
+  Knob* slot = nullptr;
   if (key && !strcmp(key, "gemm_dma")) slot = &g_use_dma;
   else if (key && !strcmp(key, "gemm_ring")) slot = &g_use_ring;
   else if (key && !strcmp(key, "gemm_ring_min_tiles")) slot = &g_ring_min_tiles;
   else if (key && !strcmp(key, "gemm_pp")) slot = &g_use_pp;
   else if (key && !strcmp(key, "gemm_p8")) slot = &g_use_p8;
   else if (key && !strcmp(key, "gemm_p8_min_tiles")) slot = &g_p8_min_tiles;
-  else if (key && !strcmp(key, "wgrad_p8")) { if (g_wgrad_p8 < 0) g_wgrad_p8 = env_int("ZS_WGRAD_P8", 1); slot = &g_wgrad_p8; }
+  else if (key && !strcmp(key, "wgrad_p8")) slot = &g_wgrad_p8;
   if (key && !strcmp(key, "gru_persist")) return zs_gru_persist_option(value);
+  if (key && !strcmp(key, "gru_spin_limit")) return zs_gru_spin_limit_option(value);
   if (!slot) { zs_set_error("zs_set_option: unknown key %s", key ? key : "(null)"); return ZS_EINVAL; }
-  const int old = *slot;
-  *slot = value;
-  return old;
+  return slot->set(value);
 }
 
 extern "C" size_t zs_gemm_wgrad_workspace_bytes(const ZsGemmWgrad* p) {
@@ -1962,12 +1961,8 @@ extern "C" int zs_gemm_wgrad(const ZsGemmWgrad* p, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   ZS_REQUIRE((int64_t)co_tiles * p->taps * ci_tiles * splits < (1ll << 31), "zs_gemm_wgrad: grid too large");
   dim3 grid((unsigned)(co_tiles * p->taps * ci_tiles * splits), 1, 1);
+  std::call_once(g_lds_attr_once, set_lds_attrs);
   if (w.p8) {
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_p8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
-      attr = true;
-    }
     hipLaunchKernelGGL(gemm_wgrad_p8_kernel, grid, dim3(PNT), P8_LDS, s, *p, ci_tiles, rows_per_split, cout_r, cin_r);
   } else if (p->dtype == ZS_F32) {
     const size_t lds = (4 * WK * WFrag<float>::PITCHW > EPI_LDS_BYTES) ? 4 * WK * WFrag<float>::PITCHW : EPI_LDS_BYTES;

@@ -9,6 +9,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "zs_common.h"
 
 extern "C" size_t zs_gru_work_bytes(int32_t B, int32_t H);
@@ -354,6 +356,8 @@ struct GruPersistArgs {
   void* gates;
   unsigned long long* hx;        // exchange granules [2 dirs][2 parities][rows_pad][gpr]; zeroed before the launch
   unsigned* err;                 // error word (behind hx), zeroed with it
+  unsigned* status;              // optional caller-owned STICKY status word: bit 0 is OR-ed in on a timeout, never cleared here
+  unsigned spin_limit;
   int B, T, H, rows_pad;
 };
 
@@ -391,7 +395,7 @@ template <> struct Pair<float> {
   }
 };
 
-constexpr unsigned GRU_SPIN_LIMIT = 1u << 21;
+constexpr unsigned GRU_SPIN_LIMIT = 1u << 21;   // default of the "gru_spin_limit" option
 
 template <typename T, int PER>     // PER = k-steps (of Frag16<T>::KSTEP) per wave: H = 4 * PER * KSTEP
 __global__ __launch_bounds__(256) void gru_persist_fwd_kernel(const GruPersistArgs a) {
@@ -476,8 +480,11 @@ __global__ __launch_bounds__(256) void gru_persist_fwd_kernel(const GruPersistAr
           }
         if (__all(ok) || dead) break;
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > GRU_SPIN_LIMIT) {
-          if (lane == 0) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (++spins > a.spin_limit) {
+          if (lane == 0) {
+            __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.status) __hip_atomic_fetch_or(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
           dead = true;
           break;
         }
@@ -548,6 +555,8 @@ struct GruPersistBwdArgs {
   void* dgh; int64_t ldgh;
   unsigned long long* dx;        // exchange granules [2 dirs][2 parities][rows_pad][3H / GPE]; zeroed before the launch
   unsigned* err;
+  unsigned* status;              // sticky status word (bit 1 = BPTT timeout), see GruPersistArgs
+  unsigned spin_limit;
   int B, T, H, rows_pad;
 };
 
@@ -624,8 +633,11 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_kernel(const GruPersistBw
         }
         if (__all(ok) || dead) break;
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > GRU_SPIN_LIMIT) {
-          if (lane == 0) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (++spins > a.spin_limit) {
+          if (lane == 0) {
+            __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.status) __hip_atomic_fetch_or(a.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
           dead = true;
           break;
         }
@@ -699,26 +711,38 @@ size_t gru_hx_bytes(int B, int H, int es) {
   const size_t rows = (size_t)((B + 16 * RB - 1) / (16 * RB)) * 16 * RB;
   return (size_t)2 * 2 * rows * ((size_t)H * es / 4) * 8;
 }
-int g_gru_persist = -1;
+// options: relaxed atomics (zs_set_option may be called from any thread; a launch reads each knob once)
+std::atomic<int> g_gru_persist{-1};
+std::atomic<int> g_gru_spin_limit{-1};
 bool gru_persist_enabled() {
-  if (g_gru_persist < 0) { const char* e = getenv("ZS_GRU_PERSIST"); g_gru_persist = e ? atoi(e) : 1; }
-  return g_gru_persist != 0;
+  int v = g_gru_persist.load(std::memory_order_relaxed);
+  if (v < 0) { const char* e = getenv("ZS_GRU_PERSIST"); v = e ? atoi(e) : 1; g_gru_persist.store(v, std::memory_order_relaxed); }
+  return v != 0;
+}
+unsigned gru_spin_limit() {
+  int v = g_gru_spin_limit.load(std::memory_order_relaxed);
+  if (v < 0) { const char* e = getenv("ZS_GRU_SPIN_LIMIT"); v = e ? atoi(e) : (int)GRU_SPIN_LIMIT; g_gru_spin_limit.store(v, std::memory_order_relaxed); }
+  return (unsigned)v;
 }
 // workgroups that are certainly co-resident: one per CU
 int64_t gru_resident_limit() {
-  static int cus = 0;
-  if (cus == 0) {
+  static std::atomic<int> cus{0};
+  int c = cus.load(std::memory_order_relaxed);
+  if (c == 0) {
     int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) c = prop.multiProcessorCount;
+    if (c <= 0) c = 256;
+    cus.store(c, std::memory_order_relaxed);
   }
-  return cus;
+  return c;
 }
 
 }  // namespace
 
 // "gru_persist" knob of zs_set_option
-int zs_gru_persist_option(int value) { const int old = gru_persist_enabled() ? 1 : 0; g_gru_persist = value ? 1 : 0; return old; }
+int zs_gru_persist_option(int value) { const int old = gru_persist_enabled() ? 1 : 0; g_gru_persist.store(value ? 1 : 0, std::memory_order_relaxed); return old; }
+// "gru_spin_limit": sweeps a persistent GRU wave waits for its group before it gives up (tests force a timeout with 0)
+int zs_gru_spin_limit_option(int value) { const int old = (int)gru_spin_limit(); g_gru_spin_limit.store(value < 0 ? 0 : value, std::memory_order_relaxed); return old; }
 
 extern "C" size_t zs_gru_work_bytes(int32_t B, int32_t H) {
   // gh [2][B][3H] + hstate/dhd [2][B][H] + dhg [2][B][H], fp32; or the persistent kernel's exchange granules (fp32 size) + error word
@@ -767,6 +791,7 @@ extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
       const size_t hx_bytes = gru_hx_bytes(B, H, es);
       a.hx = reinterpret_cast<unsigned long long*>(p->work);
       a.err = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p->work) + zs_gru_work_bytes(B, H) - 256);   // reserved tail
+      a.status = p->status; a.spin_limit = gru_spin_limit();
       a.B = B; a.T = T; a.H = H; a.rows_pad = nrb * 16 * RB;
       if (hipMemsetAsync(p->work, 0, hx_bytes, (hipStream_t)stream) != hipSuccess || hipMemsetAsync(a.err, 0, 16, (hipStream_t)stream) != hipSuccess) {
         zs_set_error("zs_gru_fwd: memset failed");
@@ -856,6 +881,7 @@ extern "C" int zs_gru_bwd(const ZsGruBwd* p, void* stream) {
       const size_t dx_bytes = gru_hx_bytes(B, 3 * H, es);
       a.dx = reinterpret_cast<unsigned long long*>(p->work);
       a.err = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p->work) + zs_gru_work_bytes(B, H) - 256);   // reserved tail
+      a.status = p->status; a.spin_limit = gru_spin_limit();
       a.B = B; a.T = T; a.H = H; a.rows_pad = nrb * 16;
       if (hipMemsetAsync(p->work, 0, dx_bytes, (hipStream_t)stream) != hipSuccess || hipMemsetAsync(a.err, 0, 16, (hipStream_t)stream) != hipSuccess) {
         zs_set_error("zs_gru_bwd: memset failed");

@@ -10,20 +10,29 @@ import torch
 
 
 class DataLoader(object):
-    def __init__(self, dataset, batch_size=16):
+    """dataloader.py:22-52.  `rank` / `world` (data parallel, not in the reference): `index` is the start of the GLOBAL
+    batch of world*batch_size consecutive items, rank r serves items [index + r*B, index + (r+1)*B) of it and every rank
+    advances by world*B with the reference's wrap rule applied to the global batch -- so the ranks never serve the same item
+    in one pass.  world == 1 is exactly the reference."""
+
+    def __init__(self, dataset, batch_size=16, rank=0, world=1):
         self.dataset = dataset
         self.n_elements = len(self.dataset[0])
         self.batch_size = batch_size
+        self.rank, self.world = int(rank), max(1, int(world))
         self.index = 0
 
     def _fetch(self, size):
-        samples = [self.dataset[self.index + i] for i in range(size)]
+        n = len(self.dataset)
+        base = self.index + self.rank * size
+        samples = [self.dataset[(base + i) % n if self.world > 1 else base + i] for i in range(size)]
         batch = [[s for s in sample] for sample in zip(*samples)]
         batch_tensor = [torch.from_numpy(np.array(data)) for data in batch]
-        if self.index + 2 * self.batch_size >= len(self.dataset):      # dataloader.py:48-51 wrap rule
+        step = self.world * self.batch_size
+        if self.index + 2 * step >= n:                                 # dataloader.py:48-51 wrap rule
             self.index = 0
         else:
-            self.index += self.batch_size
+            self.index += step
         return tuple(batch_tensor)
 
     def all(self, size=1000):
@@ -61,6 +70,9 @@ class DevicePrefetcher(object):
             self.slots[i] = sl
         src_c, src_x = (c, x) if (c.is_pinned() and x.is_pinned()) else (sl[0], sl[1])
         if src_x is sl[1]:
+            # the slot's previous H2D copy reads these pinned buffers asynchronously: the host may be several steps ahead of
+            # the GPU (graph replay, no per-step .item()), so wait for that copy before overwriting its source
+            sl[4].synchronize()
             sl[0].copy_(c); sl[1].copy_(x)          # pageable batch: stage it (a 67 MB host memcpy per step at B=256)
         # the device buffers of this slot were last read by the step issued two calls ago on the consumer's stream
         self.stream.wait_stream(torch.cuda.current_stream(self.device))

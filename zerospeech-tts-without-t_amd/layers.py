@@ -103,6 +103,30 @@ def opt_stream(device):
     return _OPT[key]
 
 
+_STATUS = {}
+
+
+def device_status(device):
+    """The sticky status word of a device (ZsGruFwd.status in zs_amd.h), shared by every Ctx on it."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _STATUS:
+        _STATUS[key] = torch.zeros(4, dtype=torch.int32, device=device)
+    return _STATUS[key]
+
+
+def check_status(device):
+    """Read the device's sticky status word (synchronises: call where the host syncs anyway) and raise if a persistent GRU
+    pass timed out since the last check -- the outputs / gradients of that step were invalid.  Clears the word."""
+    st = device_status(device)
+    v = int(st[0].item())
+    if v:
+        st.zero_()
+        raise L.ZsError('persistent GRU %s timed out waiting for its workgroup group: the results since the last check are '
+                        'invalid (status 0x%x; is another process holding CUs of this GPU?)' %
+                        (' and '.join(n for b, n in ((1, 'forward'), (2, 'BPTT')) if v & b), v))
+
+
 class Ctx(object):
     """Per-model execution context: device, compute dtype, cached buffers, split-K workspace."""
 
@@ -119,6 +143,9 @@ class Ctx(object):
         self.kc = 128 // self.es
         self._bufs = {}
         self._ws = None
+        # sticky status word of the persistent kernels (ZsGruFwd.status): OR-ed into on a bounded-spin timeout, never cleared by
+        # the library; read at the host's own sync points by check_status()
+        self.status = device_status(self.device)
         # weight gradients are only needed by the optimizer: run them on a second stream under the latency-bound
         # phases of the backward chain (GRU steps, small norms)
         self.overlap_wgrad = os.environ.get('ZS_OVERLAP_WGRAD', '1') == '1'
@@ -153,6 +180,9 @@ class Ctx(object):
     def release(self):
         self._bufs.clear()
         self._ws = None
+
+    def check_status(self):
+        check_status(self.device)
 
 
 class ConvLayer(object):
@@ -363,7 +393,7 @@ class GruLayer(object):
                whh=L.ptr(self.whh_f), ldw=self.hh_ldw, n_pad=self.hh_npad, w_gstride=self.hh_npad * self.hh_ldw,
                bhh=L.ptr(self.bhh), bhh_gstride=3 * H, out=out.ptr(), ldo=out.ld, out_col=out_col,
                gates=L.ptr(gates) if gates is not None else None, work=L.ptr(work), work_bytes=work.numel() * 4,
-               whh_interleaved=int(self.fast))
+               whh_interleaved=int(self.fast), status=L.ptr(c.status))
 
     def check(self, B):
         """Test hook: raise if the last persistent pass over this layer's work buffer timed out (synchronises)."""
@@ -377,7 +407,7 @@ class GruLayer(object):
         L.call('zs_gru_bwd', 'ZsGruBwd', c.stream, dtype=c.dt, B=B, T=T, H=H, dout=dout.ptr(), ldd=dout.ld, dout_col=dout_col,
                out=out.ptr(), ldo=out.ld, out_col=out_col, gates=L.ptr(gates), whh_t=L.ptr(self.whh_t), ldw=self.hh_ldw_t,
                n_pad=self.hh_npad_t, w_gstride=self.hh_npad_t * self.hh_ldw_t, dgi=dgi.ptr(), ldgi=dgi.ld, dgh=dgh.ptr(),
-               ldgh=dgh.ld, work=L.ptr(work), work_bytes=work.numel() * 4)
+               ldgh=dgh.ld, work=L.ptr(work), work_bytes=work.numel() * 4, status=L.ptr(c.status))
         for d in range(2):
             # dW_hh[d] = sum_t dgh_t^T h_{t-1}  (dir 0: h_{t-1} = out[t-1]; dir 1: out[t+1]) ; zero rows outside
             wgrad_call(c, dict(dtype=c.dt, dY=dgh.ptr(3 * H * d), ldy=dgh.ld, y_cols=3 * H, X=out.ptr(out_col + d * H),

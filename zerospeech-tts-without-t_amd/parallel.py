@@ -37,29 +37,62 @@ def rank():
 
 
 class GradReducer(object):
-    """Average flat gradient buffers across ranks.  start(buf) launches an asynchronous all-reduce (SUM)
-    ordered after everything already enqueued on the current stream; finish() waits for all of them and
-    applies the 1/world scale."""
+    """Sum flat gradient buffers across ranks.  start(buf) launches an asynchronous all-reduce (SUM) ordered after
+    everything already enqueued on the current stream; finish() makes the current stream wait for all of them.
+    The buffers then hold the SUM over ranks: the 1/world of the average is `scale`, which the consumer folds into
+    its own pass over the gradients (zs_adam_clip's grad_scale) -- no separate pass over 224 MB to apply it.
 
-    def __init__(self, bucket_bytes=64 << 20):
+    One collective per net by default (decoder 170 MB, encoder 54 MB: large messages run RCCL's rings at their
+    per-link rate); ZS_BUCKET_MB splits them.  ZS_REDUCE_BF16=1 sends bf16 (half the xGMI bytes, rounding once on
+    the way in; the sum is accumulated by RCCL in bf16) -- off by default, the fp32 reduce keeps the averaged
+    gradients exact to fp32."""
+
+    def __init__(self, bucket_bytes=None, bf16=None):
         self.pending = []
+        if bucket_bytes is None:
+            mb = int(os.environ.get('ZS_BUCKET_MB', '0'))
+            bucket_bytes = (mb << 20) if mb > 0 else (1 << 62)
         self.bucket_elems = max(1, bucket_bytes // 4)
+        self.bf16 = (os.environ.get('ZS_REDUCE_BF16', '0') == '1') if bf16 is None else bool(bf16)
+        self._half = {}
+
+    @property
+    def scale(self):
+        return 1.0 / world_size()
 
     def start(self, flat):
         w = world_size()
         if w == 1:
             return
         n = flat.numel()
+        if self.bf16:
+            h = self._half.get(flat.data_ptr())
+            if h is None or h.numel() != n:
+                h = self._half[flat.data_ptr()] = torch.empty(n, dtype=torch.bfloat16, device=flat.device)
+            h.copy_(flat)
+            self.pending.append((flat, h, dist.all_reduce(h, op=dist.ReduceOp.SUM, async_op=True)))
+            return
         for lo in range(0, n, self.bucket_elems):
             chunk = flat[lo:min(n, lo + self.bucket_elems)]
-            self.pending.append((chunk, dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True)))
+            self.pending.append((chunk, None, dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True)))
 
     def finish(self):
-        w = world_size()
-        for chunk, work in self.pending:
+        for dst, half, work in self.pending:
             work.wait()
-            chunk.mul_(1.0 / w)
+            if half is not None:
+                dst.copy_(half)
         self.pending = []
+
+
+def broadcast_params(nets, src=0):
+    """Make every rank start from rank `src`'s weights: the modules draw their initial parameters from torch's
+    default RNG, whose seed differs per process.  Broadcasts each net's flat fp32 parameter buffer."""
+    if world_size() == 1:
+        return
+    for net in nets:
+        flat, _ = net.flat_params()
+        dist.broadcast(flat, src=src)
+        net.mark_dirty()
 
 
 def shard_range(n_items, rank_, world):

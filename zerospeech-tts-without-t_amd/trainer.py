@@ -85,8 +85,8 @@ class AEStep(object):
         enc.train(); dec.train()
         multi = parallel.world_size() > 1
         plain = noise is None and drop_masks is None and seed is None and update
-        # multi-rank: graphs are opt-in (ZS_GRAPH_MULTI=1); the eager path keeps the standard async all-reduce flow
-        if plain and self.use_graph and (not multi or os.environ.get('ZS_GRAPH_MULTI', '0') == '1'):
+        # multi-rank: three graphs with the all-reduces launched between them (ZS_GRAPH_MULTI=0: every launch from the host)
+        if plain and self.use_graph and (not multi or os.environ.get('ZS_GRAPH_MULTI', '1') == '1'):
             return self._graph_step(x_btf, c, multi)
         if seed is None:
             seed = (self.adam_step + 1) * 0x9E3779B97F4A7C15 % (1 << 63) + parallel.rank()
@@ -129,7 +129,7 @@ class AEStep(object):
         b1, b2 = self.betas
         L.call('zs_adam_clip', 'ZsAdam', st, p=L.ptr(flat), g=L.ptr(gflat), m=L.ptr(o['m']), v=L.ptr(o['v']),
                n=flat.numel(), lr=self.lr, beta1=b1, beta2=b2, eps=1e-8, bc1=1.0, bc2=1.0, sumsq=L.ptr(o['sq']),
-               max_norm=self.max_grad_norm, write_clipped_grad=0, step_ptr=L.ptr(self._step_dev))
+               max_norm=self.max_grad_norm, write_clipped_grad=0, step_ptr=L.ptr(self._step_dev), grad_scale=self.reducer.scale)
         net.repack()
 
     def _early_decoder_update(self):
@@ -216,7 +216,9 @@ class AEStep(object):
         return {'graphs': graphs, 'x': xs, 'c': cs}
 
     def grad_norms(self):
-        """Squared per-net gradient norms as device scalars (Encoder, Decoder are clipped separately)."""
+        """Squared per-net gradient norms as device scalars (Encoder, Decoder are clipped separately).  With more than one
+        rank the gradient buffers hold the SUM over ranks after the reduce (the 1/world is applied inside zs_adam_clip):
+        these are the squared norms of that sum, i.e. world^2 times those of the averaged gradient."""
         out = []
         st = torch.cuda.current_stream(self.device).cuda_stream
         for name, net in (('enc', self.Encoder), ('dec', self.Decoder)):
@@ -238,7 +240,7 @@ class AEStep(object):
             flat, gflat = net.flat_params()
             L.call('zs_adam_clip', 'ZsAdam', st, p=L.ptr(flat), g=L.ptr(gflat), m=L.ptr(o['m']), v=L.ptr(o['v']),
                    n=flat.numel(), lr=self.lr, beta1=b1, beta2=b2, eps=1e-8, bc1=bc1, bc2=bc2, sumsq=L.ptr(o['sq']),
-                   max_norm=self.max_grad_norm, write_clipped_grad=0)
+                   max_norm=self.max_grad_norm, write_clipped_grad=0, grad_scale=self.reducer.scale)
             net.mark_dirty()
         self._step_dev.fill_(self.adam_step)
 
@@ -289,6 +291,9 @@ class ClfStep(object):
         ce, out = self._classify(logits, c, alpha_dis, seed + 1, clf_masks)
         ce.backward(self._dl, out.ld, need_dx=False)
         join_side(self.device)
+        if parallel.world_size() > 1:
+            self.ae.reducer.start(self.clf.flat_params()[1])
+            self.ae.reducer.finish()
         if update:
             self.optimizer_step()
         return self.loss, self.correct
@@ -301,7 +306,7 @@ class ClfStep(object):
         b1, b2 = self.betas
         L.call('zs_adam_clip', 'ZsAdam', st, p=L.ptr(flat), g=L.ptr(gflat), m=L.ptr(self.m), v=L.ptr(self.v), n=flat.numel(),
                lr=self.lr, beta1=b1, beta2=b2, eps=1e-8, bc1=1.0 - b1 ** self.adam_step, bc2=1.0 - b2 ** self.adam_step,
-               sumsq=L.ptr(self.sq), max_norm=self.max_grad_norm, write_clipped_grad=0)
+               sumsq=L.ptr(self.sq), max_norm=self.max_grad_norm, write_clipped_grad=0, grad_scale=self.ae.reducer.scale)
         self.clf.mark_dirty()
 
     def g_step(self, x_btf, c, alpha, seed=None, update=True, noise=None, noise_kind=2, drop_masks=None, clf_masks=None):
@@ -357,6 +362,7 @@ class Trainer(object):
             device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
         self.device = torch.device(device)
         self.log_every = int(os.environ.get('ZS_LOG_EVERY', '1'))
+        self.ckpt_every = int(os.environ.get('ZS_CKPT_EVERY', '1000'))     # the reference saves every 1000 iterations (trainer.py:345)
         self.build_model()
 
     # ---- model (trainer.py:48-98) -------------------------------------------------------------
@@ -385,6 +391,15 @@ class Trainer(object):
         self.ae = AEStep(self.Encoder, self.Decoder, lr=hps.lr, betas=(0.5, 0.9), max_grad_norm=hps.max_grad_norm)
         self.clf = ClfStep(self.ae, self.SpeakerClassifier, lr=hps.lr, betas=(0.5, 0.9), max_grad_norm=hps.max_grad_norm)
         self.testing_shift_c = None
+        self.sync_params()
+
+    def nets(self):
+        return [self.Encoder, self.Decoder, self.Generator, self.SpeakerClassifier]
+
+    def sync_params(self):
+        """Data parallel: every rank starts from rank 0's weights (each process seeds torch's RNG differently, so the freshly
+        built replicas differ); the Adam moments start at zero everywhere.  Called after build_model and load_model."""
+        parallel.broadcast_params(self.nets())
 
     def reset_keep(self):
         self.model_kept = []
@@ -423,6 +438,7 @@ class Trainer(object):
                     print('[%s - X] (%s), ' % (tag, type(e).__name__), end='')
         if verbose:
             print('Loaded!')
+        self.sync_params()
 
     # ---- inference (trainer.py:180-228) -------------------------------------------------------
     def set_eval(self):
@@ -453,13 +469,17 @@ class Trainer(object):
                 raise NotImplementedError('Invalid Generator mode!')
         elif verbose:
             print('Testing with Autoencoder only, encoding: ', enc.cpu().numpy())
-        return x_dec.cpu().numpy(), enc.cpu().numpy()
+        out = x_dec.cpu().numpy(), enc.cpu().numpy()
+        layers.check_status(self.device)                  # the .cpu() above synchronised: a timed-out GRU pass raises here
+        return out
 
     def encoder_test_step(self, x, U=None, G=None):
         self.set_eval()
         x = x.to(self.device).permute(0, 2, 1)
         enc, _ = self.Encoder(x, U=U, G=G)
-        return enc.cpu().numpy()
+        out = enc.cpu().numpy()
+        layers.check_status(self.device)
+        return out
 
     # ---- training pieces (trainer.py:238-254) --------------------------------------------------
     def permute_data(self, data, load_mel=False):
@@ -496,6 +516,7 @@ class Trainer(object):
                 loss_t = self.ae_step(x, c)
                 if (iteration % self.log_every == 0) or (iteration + 1 == hps.enc_pretrain_iters):
                     loss_rec = loss_t.item()                                              # the only host sync
+                    layers.check_status(self.device)                                      # ... so the GRU status word is read here
                     info = {f'{flag}/pre_loss_rec': loss_rec}
                     slot_value = (iteration + 1, hps.enc_pretrain_iters) + tuple(info.values())
                     if is_main:
@@ -503,8 +524,9 @@ class Trainer(object):
                         if iteration % 100 == 0:
                             for tag, value in info.items():
                                 self.logger.scalar_summary(tag, value, iteration + 1)
-                if (iteration + 1) % 1000 == 0 and is_main:
+                if (iteration + 1) % self.ckpt_every == 0 and is_main:
                     self.save_model(model_path, 'ae', iteration + 1)
+            layers.check_status(self.device)                                              # every rank, after the last step
             if is_main:
                 print()
         elif mode == 'pretrain_C':                                                        # trainer.py:349-382
@@ -513,14 +535,16 @@ class Trainer(object):
                 loss_t, corr = self.clf.d_step(x, c)
                 if (iteration % self.log_every == 0) or (iteration + 1 == hps.dis_pretrain_iters):
                     info = {f'{flag}/pre_loss_clf': loss_t.item(), f'{flag}/pre_acc': corr.item() / float(c.shape[0])}
+                    layers.check_status(self.device)
                     slot_value = (iteration + 1, hps.dis_pretrain_iters) + tuple(info.values())
                     if is_main:
                         print('pre_C:[%06d/%06d], loss_clf=%.2f, acc=%.2f' % slot_value, end='\r')
                         if iteration % 100 == 0:
                             for tag, value in info.items():
                                 self.logger.scalar_summary(tag, value, iteration + 1)
-                if (iteration + 1) % 1000 == 0 and is_main:
+                if (iteration + 1) % self.ckpt_every == 0 and is_main:
                     self.save_model(model_path, 'c', iteration + 1)
+            layers.check_status(self.device)                                              # every rank, after the last step
             if is_main:
                 print()
         elif mode == 'train':                                                             # trainer.py:384-465
@@ -545,13 +569,15 @@ class Trainer(object):
                 if log_now and is_main:
                     info = {f'{flag}/loss_rec': l_rec.item(), f'{flag}/G_loss_clf': l_clf.item(), f'{flag}/alpha': current_alpha,
                             f'{flag}/G_acc': corr.item() / float(c.shape[0])}
+                    layers.check_status(self.device)
                     print('G:[%06d/%06d], loss_rec=%.3f, loss_clf=%.2f, alpha=%.2e, acc=%.2f' % ((iteration + 1, hps.iters) + tuple(info.values())),
                           end='\r')
                     if iteration % 100 == 0:
                         for tag, value in info.items():
                             self.logger.scalar_summary(tag, value, iteration + 1)
-                if (iteration + 1) % 1000 == 0 and is_main:
+                if (iteration + 1) % self.ckpt_every == 0 and is_main:
                     self.save_model(model_path, 's1', iteration + 1)
+            layers.check_status(self.device)                                              # every rank, after the last step
             if is_main:
                 print()
         else:

@@ -20,6 +20,14 @@ def reset_grad(net_list):
         net.zero_grad()
 
 
+def grad_clip(net_list, max_grad_norm):
+    """utils.py:53-55: one clip_grad_norm_ PER net.  The training steps here never call it -- the per-net norm and the
+    clip coefficient are fused into zs_sqnorm + zs_adam_clip -- it is kept for callers of the reference's utils API and
+    works on the modules' flat gradient views (p.grad are views of one buffer per net)."""
+    for net in net_list:
+        torch.nn.utils.clip_grad_norm_(net.parameters(), max_grad_norm)
+
+
 class Logger(object):
     """tensorboardX.SummaryWriter when available (utils.py:80-85); otherwise the same (tag, value, step)
     scalars go to <log_dir>/scalars.jsonl."""
