@@ -69,6 +69,56 @@ def test_spectrogram2wav_vs_oracle(cv):
     assert np.abs(batch[0] - o).max() < 1e-3 * np.abs(o).max()
 
 
+def _speechlike(n_frames, seed):
+    """A harmonic + noise signal with a moving pitch and formant-like envelope: 200*(n_frames-1) samples at 16 kHz."""
+    rng = np.random.RandomState(seed)
+    n = 200 * (n_frames - 1)
+    t = np.arange(n) / 16000.0
+    f0 = 120 + 40 * np.sin(2 * np.pi * 0.7 * t)
+    ph = 2 * np.pi * np.cumsum(f0) / 16000.0
+    y = sum((0.5 / k) * np.sin(k * ph + rng.rand() * 6.28) * (1 + 0.5 * np.sin(2 * np.pi * (0.3 + 0.1 * k) * t)) for k in range(1, 24))
+    y = y * (0.2 + 0.8 * (np.sin(2 * np.pi * 1.3 * t) > -0.3)) + 0.02 * rng.randn(n)
+    return (0.2 * y / np.abs(y).max()).astype(np.float32)
+
+
+def test_deemphasis_kernel_vs_scipy_lfilter(cv):
+    """zs_gl_deemphasis on a 140 000-sample row (an 8.75 s utterance) against scipy.signal.lfilter([1], [1, -0.97], x), the
+    reference's own call (convert.py:60).  The recursion y[n] = x[n] + 0.97 y[n-1] is a scan on the GPU (fp32)."""
+    import scipy.signal
+    from zs_amd import _lib as L
+    dev = torch.device('cuda:0')
+    rng = np.random.RandomState(1)
+    T = 701
+    n = 200 * (T - 1)
+    x = (rng.randn(2, n) * 0.1).astype(np.float32)
+    x[1, 90000:] = 0                                               # second row shorter: only its own length is filtered
+    lens = torch.tensor([T, 451], dtype=torch.int32, device=dev)
+    w = torch.from_numpy(x).to(dev)
+    L.check(L.lib().zs_gl_deemphasis(L.ptr(w), n, L.ptr(lens), 2, 0.97, torch.cuda.current_stream().cuda_stream), 'zs_gl_deemphasis')
+    got = w.cpu().numpy()
+    for i, m in enumerate((n, 200 * 450)):
+        ref = scipy.signal.lfilter([1], [1, -0.97], x[i, :m].astype(np.float64))
+        err = np.abs(got[i, :m] - ref).max() / np.abs(ref).max()
+        assert err < 1e-3, (i, err)
+    print('deemphasis rel err', err)
+
+
+@pytest.mark.parametrize('n_iter', [8, 60])
+def test_griffin_lim_audio_700_frames_vs_oracle(cv, n_iter):
+    """A 700-frame utterance (the longest of BASELINE config 4): audio of the GPU Griffin-Lim against the oracle's at the
+    north_star tolerance, 1e-3 of the waveform scale, after 8 and after 60 iterations."""
+    import zs_oracle as O
+    y = _speechlike(700, 2)
+    S = np.abs(O.stft(y)).astype(np.float32)                       # [513, 700]
+    w_gpu = cv.griffin_lim(S, n_iter=n_iter)
+    w_ref = O.griffin_lim(S, n_iter=n_iter)
+    assert w_gpu.shape == w_ref.shape == (200 * 699,)
+    err = np.abs(w_gpu - w_ref).max() / np.abs(w_ref).max()
+    rms = np.sqrt(np.mean((w_gpu - w_ref) ** 2)) / np.sqrt(np.mean(w_ref ** 2))
+    print('GL %d iterations, 700 frames: max err %.3g of scale, rms err %.3g' % (n_iter, err, rms))
+    assert err < 1e-3, err
+
+
 def test_griffin_lim_300_iterations_converges_like_oracle(cv):
     """n_iter = 300 (hps/hps.py:31): compare spectral convergence |STFT(x)| vs target of GPU and oracle results."""
     import zs_oracle as O

@@ -139,3 +139,36 @@ def test_vocoder_regression():
     St = torch.stft(torch.from_numpy(d['stft_in']), 1024, 200, window=win, center=True, pad_mode='reflect',
                     return_complex=True).numpy()
     assert np.abs(S - St).max() < 5e-4
+
+
+def test_vocoder_pieces_pinned_to_scipy():
+    """What CAN be pinned in the vocoder oracle: scipy IS the reference's dependency for the de-preemphasis filter
+    (`signal.lfilter([1], [1, -hp.preemphasis], wav)`, convert.py:60) and, through librosa, for the window
+    (`scipy.signal.get_window('hann', win_length, fftbins=True)` centre-padded to n_fft); the STFT framing is checked
+    against scipy.signal.stft on the reflect-padded signal.  librosa-specific conventions (istft normalisation, trim) stay
+    'parity unpinned'."""
+    import scipy.signal
+    rng = np.random.RandomState(0)
+    x = (rng.randn(140000) * 0.1).astype(np.float32)
+    ref = scipy.signal.lfilter([1], [1, -0.97], x)
+    got = O.de_preemphasis(x)
+    assert got.dtype == ref.dtype == np.float64 and got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+    w = scipy.signal.get_window('hann', 800, fftbins=True)
+    pad = np.zeros(1024)
+    pad[112:912] = w                                                 # librosa.util.pad_center(w, 1024)
+    assert np.array_equal(O.hann_padded(), pad.astype(np.float32))
+    # framing + transform: scipy.signal.stft without its own padding on the reflect-padded signal; 'spectrum' scaling
+    # divides by sum(window)
+    y = x[:200 * 50]
+    yp = np.pad(y, 512, mode='reflect')
+    _, _, Z = scipy.signal.stft(yp, window=pad, nperseg=1024, noverlap=1024 - 200, nfft=1024, boundary=None, padded=False,
+                                return_onesided=True, scaling='spectrum')
+    S = O.stft(y)
+    assert S.shape == Z.shape == (513, 1 + len(y) // 200)
+    assert np.abs(S - Z * pad.sum()).max() < 1e-4 * np.abs(S).max()
+    # preprocess.py:240 pre-emphasis np.append(y[0], y[1:] - 0.97*y[:-1]) is lfilter([1, -0.97], [1], y)
+    pre = np.append(y[0], y[1:] - O.PREEMPH * y[:-1])
+    assert np.abs(pre - scipy.signal.lfilter([1, -0.97], [1], y.astype(np.float64))).max() < 1e-6
+    # ... and de_preemphasis inverts it
+    assert np.abs(O.de_preemphasis(pre) - y).max() < 1e-4
