@@ -3,10 +3,11 @@
   python main.py --preprocess [--remake]                  (wav directories -> dataset container + index JSONs)
   python main.py --train_ae [--load_model] [--hps_path hps/zerospeech_english_1024.json] [--synthetic]
   python main.py --test --enc_only | --test_encode        (needs the preprocessed HDF5 + a checkpoint)
+  python main.py --test_single --s_speaker S015 --t_speaker V002 [--enc_only]      (one wav -> result.wav + result.txt)
 
 Multi-GPU training: `python -m torch.distributed.run --nproc-per-node N main.py --train_ae ...` (one
 process per GPU; gradients are averaged with RCCL).  Modes outside the stage-1 autoencoder path
-(--train_p, --train_tgat, --train_al, --train_c, --train_t, --cross_test, --test_single,
+(--train_p, --train_tgat, --train_al, --train_c, --train_t, --cross_test,
 --test_classify, --encode, --test_asr) are not part of this build and exit with a clear error.
 """
 import argparse
@@ -16,13 +17,13 @@ import sys
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-OUT_OF_SCOPE = ['train_p', 'train_tgat', 'train_al', 'train_c', 'train_t', 'test_asr', 'cross_test', 'test_single',
-                'test_classify', 'encode']
+OUT_OF_SCOPE = ['train_p', 'train_tgat', 'train_al', 'train_c', 'train_t', 'test_asr', 'cross_test', 'test_classify', 'encode']
 
 
 def build_parser():
     p = argparse.ArgumentParser(description='zerospeech_project (MI355X autoencoder hot path)')
-    for flag in ['preprocess', 'train', 'train_ae', 'test', 'test_encode', 'load_model', 'enc_only', 'remake', 'synthetic'] + OUT_OF_SCOPE:
+    for flag in ['preprocess', 'train', 'train_ae', 'test', 'test_encode', 'test_single', 'load_model', 'enc_only', 'remake',
+                 'synthetic'] + OUT_OF_SCOPE:
         p.add_argument('--' + flag, default=False, action='store_true')
     p.add_argument('--flag', type=str, default='train')
     p.add_argument('--g_mode', default='set_from_hps',
@@ -48,6 +49,8 @@ def build_parser():
     p.add_argument('--load_train_model_name', type=str, default='model.pth-ae-424000')
     p.add_argument('--load_test_model_name', type=str, default='model.pth-s2-150000')
     p.add_argument('--ckpt_pth', type=str, default=None)
+    p.add_argument('--s_speaker', type=str, default='S015')
+    p.add_argument('--t_speaker', type=str, default='V002')
     return p
 
 
@@ -81,7 +84,7 @@ def main(argv=None):
     if bad:
         raise NotImplementedError('--%s is outside the stage-1 autoencoder hot path this build covers' % bad[0])
     from zs_amd import parallel
-    from zs_amd.convert import get_trainer, test_encode, test_from_list
+    from zs_amd.convert import get_trainer, test_encode, test_from_list, test_single
     from zs_amd.dataloader import DataLoader, Dataset, SyntheticDataset
     from zs_amd.trainer import Trainer
 
@@ -106,7 +109,7 @@ def main(argv=None):
         trainer.train(model_path, args.flag, mode='pretrain_AE')
         trainer.reset_keep()
 
-    if args.test or args.test_encode:
+    if args.test or args.test_encode or args.test_single:
         os.makedirs(args.result_dir, exist_ok=True)
         model_path = args.ckpt_pth if args.ckpt_pth is not None else os.path.join(args.ckpt_dir, args.load_test_model_name)
         trainer = get_trainer(args.hps_path, model_path, args.g_mode, args.enc_mode, None)
@@ -114,6 +117,8 @@ def main(argv=None):
         os.makedirs(result_dir, exist_ok=True)
         if args.test:
             test_from_list(trainer, hps.seg_len, args.synthesis_list, args.dataset_path, args.speaker2id_path, result_dir, args.enc_only)
+        if args.test_single:                              # main.py:190-191
+            test_single(trainer, hps.seg_len, args.speaker2id_path, args.result_dir, args.enc_only, args.s_speaker, args.t_speaker)
         if args.test_encode:
             test_encode(trainer, hps.seg_len, args.test_path, args.dataset_path, result_dir, flag='test')
 

@@ -127,3 +127,29 @@ def test_preprocess_end_to_end(tmp_path):
     assert len(outs) == 1 and outs[0].endswith('.txt')
     rows = open(str(tmp_path / 'result' / 'test' / outs[0])).read().strip().split('\n')
     assert all(set(r.split(' ')) <= {'0', '1'} and len(r.split(' ')) == 16 for r in rows)
+    # ... --test (convert.py:224-265): a synthesis list "test/<spk>_<utt> <target>" -> one PCM16 wav per line, named <target>_<utt>.wav,
+    # of at most 200*(T_out-1) samples (Griffin-Lim output, trimmed)
+    import json
+    import wave
+    syn = str(tmp_path / 'synthesis.txt')
+    open(syn, 'w').write('test/S015_0099 V002\ntest/S015_0099 V001\n')
+    spk2id = str(tmp_path / 'spk2id.json')
+    json.dump({'V001': 0, 'V002': 1, 'S015': 2, 'S020': 3}, open(spk2id, 'w'))
+    from zs_amd.hps import hp
+    n_iter, hp.n_iter = hp.n_iter, 4                                           # keep the test short; 300 in the product
+    try:
+        cv.test_from_list(tr, 64, syn, ds_path, spk2id, str(tmp_path / 'result'), enc_only=True)
+        wavs = sorted(f for f in os.listdir(str(tmp_path / 'result' / 'test')) if f.endswith('.wav'))
+        assert wavs == ['V001_0099.wav', 'V002_0099.wav']
+        T_in = store['test/S015/0099/lin'].shape[0]
+        with wave.open(str(tmp_path / 'result' / 'test' / wavs[0])) as f:
+            assert (f.getframerate(), f.getsampwidth(), f.getnchannels()) == (16000, 2, 1) and 0 < f.getnframes() <= 200 * (8 * ((T_in + 7) // 8) - 1)
+        # ... --test_single (convert.py:303-340): wav file -> result.wav + result.txt
+        single = str(tmp_path / 'single')
+        os.makedirs(single)
+        wav_data, enc = cv.test_single(tr, 64, spk2id, single, True, 'S015', 'V002', filename=str(dirs['test'] / 'S015_0099.wav'))
+        assert sorted(os.listdir(single)) == ['result.txt', 'result.wav'] and enc.shape[1] == 16 and wav_data.dtype == np.float32
+        with pytest.raises(NotImplementedError):
+            cv.test_single(tr, 64, spk2id, single, True, 'S999', 'V002')
+    finally:
+        hp.n_iter = n_iter

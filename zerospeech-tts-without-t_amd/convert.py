@@ -308,6 +308,36 @@ def test_from_list(trainer, seg_len, synthesis_list, data_path, speaker2id_path,
                     save=['wav'])
 
 
+SINGLE_FILES = {            # convert.py:308-317: the utterances --test_single knows per source speaker
+    'S015': './data/english/train/unit/S015_0361841101.wav',
+    'S119': './data/english/train/unit/S119_1561145062.wav',
+    'S130': './data/english/test/S130_3516588097.wav',
+    'S089': './data/english/test/S089_1810826781.wav',
+    'S378': './data/surprise/test/S378_117437.wav',
+}
+
+
+def test_single(trainer, seg_len, speaker2id_path, result_dir, enc_only, s_speaker, t_speaker, filename=None):
+    """convert.py:303-340: one wav -> spectrogram (zs_amd.preprocess, STFT on the GPU) -> convert() -> result.wav (PCM16) +
+    result.txt.  The reference then scores both files with the Google Web Speech API (convert.py:96-113); that needs the
+    network and is not reproduced.  `filename` overrides the per-speaker table (not in the reference signature)."""
+    from .preprocess import get_spectrograms
+    with open(speaker2id_path, 'r') as f_json:
+        speaker2id = json.load(f_json)
+    if filename is None:
+        if s_speaker not in SINGLE_FILES:
+            raise NotImplementedError('Please modify path manually!')
+        filename = SINGLE_FILES[s_speaker]
+    _, spec = get_spectrograms(filename)
+    wav_data, encodings = convert(trainer, seg_len, src_speaker_spec=spec, src_speaker=s_speaker, tar_speaker=t_speaker, utt_id='',
+                                  speaker2id=speaker2id, result_dir=result_dir, enc_only=enc_only, save=[])
+    write_wav(os.path.join(result_dir, 'result.wav'), wav_data, hp.sr)
+    write_encodings(os.path.join(result_dir, 'result.txt'), encodings)
+    print('Testing on source speaker {} and target speaker {}, output shape: {}'.format(s_speaker, t_speaker, wav_data.shape))
+    print('Comparing ASR result - skipped (the reference calls the Google Web Speech API here; no network)')
+    return wav_data, encodings
+
+
 def test_encode(trainer, seg_len, test_path, data_path, result_dir, flag='test'):
     """convert.py:342-360."""
     files = sorted(glob.glob(os.path.join(test_path, '*.wav')))

@@ -1789,6 +1789,8 @@ struct Knob {
   int set(int nv) { const int old = get(); v.store(nv < 0 ? 0 : nv, std::memory_order_relaxed); return old; }
 };
 Knob g_wgrad_p8("ZS_WGRAD_P8", 1);
+Knob g_wgrad_wgs("ZS_WGRAD_WGS", 256);      // workgroups one weight-gradient launch aims for (split-K plan of the 256x256 kernel)
+Knob g_wgrad_slab_cost("ZS_WGRAD_SLAB_COST", 13);   // cost of one split's slab write + re-read in K-tile times
 
 struct WgradPlan { int p8, splits, tile, co_tiles, ci_tiles, cout_r, cin_r, rows_per_split; };
 
@@ -1812,10 +1814,12 @@ WgradPlan wgrad_plan(const ZsGemmWgrad* p) {
     w.splits = p->splits;
   } else if (w.p8) {
     const int64_t kt = (M + 63) / 64;
+    const int64_t wgs = g_wgrad_wgs.get() > 0 ? g_wgrad_wgs.get() : 256;
+    const double slab_cost = (double)g_wgrad_slab_cost.get();
     double best = 1e30; int bs = 1;
     for (int sp = 1; sp <= 64 && (int64_t)sp * 4 <= kt; ++sp) {
-      const double rounds = (double)((tiles * sp + 255) / 256);
-      const double cost = rounds * ((double)((kt + sp - 1) / sp) + 13.0);
+      const double rounds = (double)((tiles * sp + wgs - 1) / wgs);
+      const double cost = rounds * ((double)((kt + sp - 1) / sp) + slab_cost);
       if (cost < best - 1e-9) { best = cost; bs = sp; }
     }
     w.splits = bs;
@@ -1926,6 +1930,8 @@ extern "C" int zs_set_option(const char* key, int value) {
   else if (key && !strcmp(key, "gemm_p8")) slot = &g_use_p8;
   else if (key && !strcmp(key, "gemm_p8_min_tiles")) slot = &g_p8_min_tiles;
   else if (key && !strcmp(key, "wgrad_p8")) slot = &g_wgrad_p8;
+  else if (key && !strcmp(key, "wgrad_wgs")) slot = &g_wgrad_wgs;
+  else if (key && !strcmp(key, "wgrad_slab_cost")) slot = &g_wgrad_slab_cost;
   if (key && !strcmp(key, "gru_persist")) return zs_gru_persist_option(value);
   if (key && !strcmp(key, "gru_spin_limit")) return zs_gru_spin_limit_option(value);
   if (!slot) { zs_set_error("zs_set_option: unknown key %s", key ? key : "(null)"); return ZS_EINVAL; }
