@@ -359,6 +359,23 @@ typedef struct {
   float* spec;
 } ZsGlStft;
 int zs_gl_stft_project(const ZsGlStft* p, void* stream);
+/* zs_gl_iter: ONE Griffin-Lim iteration (convert.py:46-50) as one fused kernel per utterance tile:
+ *     x = istft(spec_in);  E = stft(x);  spec_out = mag * E / max(1e-8, |E|)
+ * (the windowed frames and the waveform never leave LDS; 512-point complex FFT per wave for the real 1024-point transforms).
+ * spec_out == NULL: the final pass -- only x = istft(spec_in), written to wav [n_utt][wav_ld] (200*(T-1) samples each).
+ * spec_in / spec_out: complex64 [n_utt][T_max][513], distinct buffers (neighbouring tiles read spec_in while spec_out is
+ * written).  Utterances need lengths[u] >= 4 frames (the reflect padding of 512 samples must fit; shorter ones are skipped:
+ * the reference's decoder never emits fewer than 16).
+ * zs_griffin_lim: the whole loop of convert.py:39-52 from one call: spec_a holds X0 = S (zero phase) on entry; n_iter
+ * iterations ping-pong spec_a / spec_b; then the final inverse pass into wav. */
+typedef struct {
+  const float* spec_in; float* spec_out;
+  const float* mag; const int32_t* lengths; int32_t n_utt, T_max;
+  float* wav; int64_t wav_ld;
+  int32_t tile_frames;           /* STFT frames per workgroup tile (4..42), 0 = default 26 */
+} ZsGlIter;
+int zs_gl_iter(const ZsGlIter* p, void* stream);
+int zs_griffin_lim(const ZsGlIter* p, float* spec_a, float* spec_b, int32_t n_iter, void* stream);
 /* spectrogram2wav pre/post (convert.py:56-60): de-normalise to amplitude; de-preemphasis IIR. */
 /* ---------------------------------------------------------------------------------------------
  * Feature extraction feeding the path (preprocess.py:227-258 get_spectrograms after the host-side

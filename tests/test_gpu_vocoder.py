@@ -51,6 +51,58 @@ def test_stft_istft_kernels(cv):
     assert np.abs(got - E).max() < 2e-4 * np.abs(E).max()
 
 
+@pytest.mark.parametrize('T,tile', [(4, 0), (5, 4), (17, 4), (40, 10), (53, 26), (131, 0), (131, 42)])
+def test_fused_griffin_lim_iteration_vs_oracle(cv, T, tile):
+    """zs_gl_iter (one fused kernel: istft -> overlap-add -> stft -> projection, 512-point complex FFT per wave) against the
+    oracle's istft / stft on a random complex spectrogram, for every tile size class: single tile, many small tiles (halo
+    frames from both neighbours), utterance ends inside a tile.  With mag = |E_ref| the projection reproduces E itself.
+    Tolerance 2e-4 of the scale (fp32 transforms, different butterfly order than numpy's)."""
+    import zs_oracle as O
+    from zs_amd import _lib as L
+    dev = torch.device('cuda:0')
+    st = torch.cuda.current_stream().cuda_stream
+    rng = np.random.RandomState(T)
+    X = (rng.randn(513, T) + 1j * rng.randn(513, T)).astype(np.complex64)
+    x_ref = O.istft(X)
+    E = O.stft(x_ref)
+    Tm = T + 3                                                      # T_max > T: rows past the length must stay untouched
+    spec_in = torch.zeros(1, Tm, 513, 2, device=dev)
+    spec_in[0, :T, :, 0] = torch.from_numpy(np.ascontiguousarray(X.real.T)).to(dev)
+    spec_in[0, :T, :, 1] = torch.from_numpy(np.ascontiguousarray(X.imag.T)).to(dev)
+    spec_out = torch.full((1, Tm, 513, 2), 7.0, device=dev)
+    mag = torch.zeros(1, Tm, 513, device=dev)
+    mag[0, :T] = torch.from_numpy(np.ascontiguousarray(np.abs(E).T)).to(dev)
+    lengths = torch.tensor([T], dtype=torch.int32, device=dev)
+    wav = torch.full((1, 200 * (Tm - 1)), 3.0, device=dev)
+    L.call('zs_gl_iter', 'ZsGlIter', st, spec_in=L.ptr(spec_in), spec_out=L.ptr(spec_out), mag=L.ptr(mag), lengths=L.ptr(lengths), n_utt=1,
+           T_max=Tm, wav=L.ptr(wav), wav_ld=wav.shape[1], tile_frames=tile)
+    L.call('zs_gl_iter', 'ZsGlIter', st, spec_in=L.ptr(spec_in), spec_out=None, mag=L.ptr(mag), lengths=L.ptr(lengths), n_utt=1,
+           T_max=Tm, wav=L.ptr(wav), wav_ld=wav.shape[1], tile_frames=tile)
+    torch.cuda.synchronize()
+    got = (spec_out[0, :T, :, 0] + 1j * spec_out[0, :T, :, 1]).cpu().numpy().T
+    assert np.abs(got - E).max() < 2e-4 * np.abs(E).max(), np.abs(got - E).max() / np.abs(E).max()
+    assert (spec_out[0, T:] == 7.0).all()
+    w = wav[0].cpu().numpy()
+    assert np.abs(w[:200 * (T - 1)] - x_ref).max() < 2e-4 * np.abs(x_ref).max()
+    assert (w[200 * (T - 1):] == 3.0).all()
+
+
+def test_fused_griffin_lim_equals_split_kernels_and_is_tile_invariant(cv):
+    """Ragged batch, 12 iterations: the fused loop (zs_griffin_lim) agrees with the per-transform kernels it replaces to 1e-3 of
+    the scale, and its result does not depend on the tile size bit for bit (the overlap-add order is fixed by frame index mod 4)."""
+    rng = np.random.RandomState(9)
+    mags = [np.abs(rng.randn(513, T)).astype(np.float32) * np.linspace(1, 0.01, 513, dtype=np.float32)[:, None] for T in (16, 61, 300, 97)]
+    ref, _, lens = cv.griffin_lim_batch(mags, n_iter=12, impl='split')
+    outs = [cv.griffin_lim_batch(mags, n_iter=12, impl='fused', tile_frames=f)[0] for f in (0, 10, 42)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    for i, T in enumerate(lens):
+        a, b = outs[0][i, :200 * (T - 1)].cpu().numpy(), ref[i, :200 * (T - 1)].cpu().numpy()
+        assert np.abs(a - b).max() < 1e-3 * np.abs(b).max(), (T, np.abs(a - b).max() / np.abs(b).max())
+        assert (outs[0][i, 200 * (T - 1):] == 0).all()
+    with pytest.raises(ValueError):
+        cv.griffin_lim_batch([mags[0][:, :3]], n_iter=1)
+
+
 def test_spectrogram2wav_vs_oracle(cv):
     import zs_oracle as O
     d, _ = load_golden('vocoder_small.npz')

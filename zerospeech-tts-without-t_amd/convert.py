@@ -32,16 +32,20 @@ def _device():
     return torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
 
 
-def griffin_lim_batch(mags, n_iter=None, device=None):
-    """mags: list of real [513, T_i] amplitude spectrograms.  Returns list of float32 wavs of 200*(T_i-1) samples.
-    X = S (zero phase); n_iter x { x = istft(X); E = stft(x); X = S * E / max(1e-8, |E|) }; x = istft(X)."""
+def griffin_lim_batch(mags, n_iter=None, device=None, impl=None, tile_frames=0):
+    """mags: list of real [513, T_i] amplitude spectrograms.  Returns (wav [n, 200*(T_max-1)] on the device, lengths, lens).
+    X = S (zero phase); n_iter x { x = istft(X); E = stft(x); X = S * E / max(1e-8, |E|) }; x = istft(X)  (convert.py:39-52).
+    impl 'fused' (default): zs_griffin_lim -- one fused kernel per iteration, the whole loop issued by one C call;
+    impl 'split' (ZS_GL_IMPL=split): the older per-transform kernels (zs_gl_istft + zs_gl_stft_project per iteration), kept as
+    the variant the tests compare the fused kernel with."""
     n_iter = hp.n_iter if n_iter is None else n_iter
+    impl = impl or os.environ.get('ZS_GL_IMPL', 'fused')
     dev = device or _device()
     st = torch.cuda.current_stream(dev).cuda_stream
     n = len(mags)
     lens = [int(m.shape[1]) for m in mags]
-    if min(lens) < 2:
-        raise ValueError('griffin_lim needs at least 2 frames')
+    if min(lens) < 4:
+        raise ValueError('griffin_lim needs at least 4 frames (reflect padding of n_fft//2 = 512 samples on 200*(T-1) samples)')
     Tm = max(lens)
     mag = torch.zeros(n, Tm, 513, dtype=torch.float32, device=dev)
     for i, m in enumerate(mags):
@@ -52,6 +56,14 @@ def griffin_lim_batch(mags, n_iter=None, device=None):
     spec[..., 0] = mag
     wav_ld = 200 * (Tm - 1)
     wav = torch.zeros(n, wav_ld, dtype=torch.float32, device=dev)
+    if impl == 'fused':
+        spec_b = torch.empty_like(spec)
+        S = L.STRUCTS['ZsGlIter'](mag=L.ptr(mag), lengths=L.ptr(lengths), n_utt=n, T_max=Tm, wav=L.ptr(wav), wav_ld=wav_ld,
+                                  tile_frames=int(tile_frames))
+        L.check(L.lib().zs_griffin_lim(ctypes.addressof(S), L.ptr(spec), L.ptr(spec_b), int(n_iter), st), 'zs_griffin_lim')
+        return wav, lengths, lens
+    if impl != 'split':
+        raise ValueError("griffin_lim impl must be 'fused' or 'split'")
     frames = torch.empty(n, Tm, 1024, dtype=torch.float32, device=dev)
     ist = dict(spec=L.ptr(spec), mag=L.ptr(mag), lengths=L.ptr(lengths), n_utt=n, T_max=Tm, wav=L.ptr(wav), wav_ld=wav_ld,
                frames_ws=L.ptr(frames))
@@ -63,9 +75,9 @@ def griffin_lim_batch(mags, n_iter=None, device=None):
     return wav, lengths, lens
 
 
-def griffin_lim(spectrogram, n_iter=None):
+def griffin_lim(spectrogram, n_iter=None, impl=None):
     """convert.py:39-52 for one [513, T] amplitude spectrogram."""
-    wav, _, lens = griffin_lim_batch([spectrogram], n_iter=n_iter)
+    wav, _, lens = griffin_lim_batch([spectrogram], n_iter=n_iter, impl=impl)
     return wav[0, :200 * (lens[0] - 1)].cpu().numpy()
 
 

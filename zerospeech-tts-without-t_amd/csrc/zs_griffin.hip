@@ -1,0 +1,314 @@
+// zs_griffin.hip -- one Griffin-Lim iteration as ONE kernel (reference convert.py:39-52 on librosa stft / istft):
+//     x = istft(X);  E = stft(x);  X' = S * E / max(1e-8, |E|)
+// fused per utterance tile so that neither the windowed frames nor the waveform ever leave LDS.
+//
+// gfx950 design
+//  * A workgroup (4 waves) owns a tile of F consecutive STFT frames [t0, t1) of one utterance.  With the hann(800) window
+//    centred in the 1024-sample frame a waveform sample is touched by exactly 4 frames and an output frame depends on the
+//    input frames t-3 .. t+3: the tile inverse-transforms F + 6 frames (3 halo frames per side, 23 % extra inverse work at
+//    F = 26), overlap-adds them into an LDS segment of (F-1)*200 + 800 samples, divides by the window-sum-square, and
+//    transforms its own F frames forward.  HBM / Infinity-Cache traffic per frame and iteration: the spectrogram once in
+//    and once out (2 x 4.1 KB) + the halo re-reads -- against ~25 KB for the unfused frames -> overlap-add -> frames chain.
+//  * Frames whose indices are equal mod 4 never overlap (4 * hop = 800 = window length), so the overlap-add runs in four
+//    phases, one residue each, with plain non-atomic LDS accumulation: deterministic, no race.
+//  * The transform is a 512-point complex FFT per WAVE (real 1024-point transform through the even/odd packing: half the
+//    butterflies of the complex 1024-point FFT): three radix-8 Stockham passes with the 8 points of a butterfly in registers,
+//    two wave-private LDS exchanges between them (skewed by i + i/8 -> every ds access pattern of the three passes is
+//    bank-conflict free for a half-wave), no workgroup barrier inside the transform.  Twiddles: one LDS table of the
+//    1024th roots of unity per workgroup (the 512th and 64th roots are strided views), powers w^2..w^7 by multiplication.
+//  * Twiddle table, window and segment share 49 KB of LDS at F = 26 -> three workgroups (12 waves) per CU.
+// zs_griffin_lim runs the whole loop (n_iter launches ping-ponging two spectrogram buffers + the final inverse pass) from
+// one C call.  The older one-transform-per-workgroup kernels (zs_vocoder.hip) remain as the variant the tests compare with.
+#include "zs_common.h"
+
+namespace {
+
+constexpr int NB = 513, HOP = 200, WLEN = 800, WOFF = 112, HALF = 512;
+constexpr int WBUF = 576;      // complex slots of a wave's exchange buffer: 512 + 512/8 skew
+constexpr int NWAVE = 4;
+constexpr int WTAB = 520;      // 513 roots, padded
+
+__device__ __forceinline__ int padi(int i) { return i + (i >> 3); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// LDS hand-off between the lanes of ONE wave: LDS instructions of a wave execute in order, so a later ds_read sees an earlier
+// ds_write of any lane; the wait + barrier only stop the compiler from moving accesses across this point.
+__device__ __forceinline__ void wave_lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// 8-point DFT in registers, natural-order output.  INV = false: kernel exp(-2 pi i rq/8); true: exp(+2 pi i rq/8).
+template <bool INV>
+__device__ __forceinline__ void dft8(float2 (&v)[8]) {
+  constexpr float S = 0.70710678118654752f;
+  const float2 t0 = cadd(v[0], v[4]), t1 = csub(v[0], v[4]);
+  const float2 t2 = cadd(v[2], v[6]), t3 = csub(v[2], v[6]);
+  const float2 t4 = cadd(v[1], v[5]), t5 = csub(v[1], v[5]);
+  const float2 t6 = cadd(v[3], v[7]), t7 = csub(v[3], v[7]);
+  const float2 e0 = cadd(t0, t2), e1 = csub(t0, t2), e2 = cadd(t4, t6), e3 = csub(t4, t6);
+  // w4 * z : forward -i z = (z.y, -z.x); inverse +i z = (-z.y, z.x)
+  const float2 w4e3 = INV ? make_float2(-e3.y, e3.x) : make_float2(e3.y, -e3.x);
+  v[0] = cadd(e0, e2); v[4] = csub(e0, e2);
+  v[2] = cadd(e1, w4e3); v[6] = csub(e1, w4e3);
+  const float2 u1 = INV ? make_float2(S * (t5.x - t5.y), S * (t5.x + t5.y)) : make_float2(S * (t5.x + t5.y), S * (t5.y - t5.x));
+  const float2 u2 = INV ? make_float2(-t3.y, t3.x) : make_float2(t3.y, -t3.x);
+  const float2 u3 = INV ? make_float2(S * (-t7.x - t7.y), S * (t7.x - t7.y)) : make_float2(S * (t7.y - t7.x), S * (-t7.x - t7.y));
+  const float2 o0 = cadd(t1, u2), o1 = csub(t1, u2), o2 = cadd(u1, u3), o3 = csub(u1, u3);
+  const float2 w4o3 = INV ? make_float2(-o3.y, o3.x) : make_float2(o3.y, -o3.x);
+  v[1] = cadd(o0, o2); v[5] = csub(o0, o2);
+  v[3] = cadd(o1, w4o3); v[7] = csub(o1, w4o3);
+}
+
+// v[r] *= w1^r, r = 1..7
+__device__ __forceinline__ void twiddle8(float2 (&v)[8], float2 w1) {
+  const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2), w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3);
+  v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
+  v[5] = cmul(v[5], w5); v[6] = cmul(v[6], w6); v[7] = cmul(v[7], w7);
+}
+
+// 512-point complex FFT of one wave.  Lane j holds elements j + 64 r (r = 0..7) on entry and the natural-order result in the
+// same layout on exit.  Stockham radix-8: pass with Ns = 1, 8, 64: butterfly j reads x[j + 64 r], multiplies by
+// exp(-+2 pi i r (j mod Ns) / (8 Ns)), and writes y[(j / Ns) 8 Ns + (j mod Ns) + r Ns].  W = exp(-2 pi i k / 1024).
+template <bool INV>
+__device__ __forceinline__ void fft512(float2 (&v)[8], float2* buf, const float2* W, int lane) {
+  dft8<INV>(v);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) buf[9 * lane + r] = v[r];                    // padi(8 lane + r)
+  wave_lds_sync();
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = buf[padi(lane + 64 * r)];
+  wave_lds_sync();
+  {
+    float2 w1 = W[16 * (lane & 7)];                                        // 64th roots
+    if (INV) w1.y = -w1.y;
+    twiddle8(v, w1);
+  }
+  dft8<INV>(v);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) buf[padi(((lane >> 3) << 6) + (lane & 7) + 8 * r)] = v[r];
+  wave_lds_sync();
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = buf[padi(lane + 64 * r)];
+  wave_lds_sync();
+  {
+    float2 w1 = W[2 * lane];                                               // 512th roots
+    if (INV) w1.y = -w1.y;
+    twiddle8(v, w1);
+  }
+  dft8<INV>(v);
+}
+
+__device__ __forceinline__ int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+__global__ __launch_bounds__(256) void gl_iter_kernel(const ZsGlIter p, const float* spec_in, float* spec_out, int F) {
+  extern __shared__ __align__(16) unsigned char gl_smem[];
+  float2* W = reinterpret_cast<float2*>(gl_smem);
+  float* win = reinterpret_cast<float*>(W + WTAB);
+  float2* wb = reinterpret_cast<float2*>(win + WLEN);
+  float* seg = reinterpret_cast<float*>(wb + NWAVE * WBUF);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int u = blockIdx.y;
+  const int T = p.lengths[u];
+  if (T < 4) return;                                                         // reflect padding of 512 needs >= 513 samples
+  const int nt = (T + F - 1) / F, tile = blockIdx.x;
+  if (tile >= nt) return;
+  const int t0 = (int)((int64_t)tile * T / nt), t1 = (int)((int64_t)(tile + 1) * T / nt);   // balanced tiles, each >= 2 frames
+  const int L = HOP * (T - 1);
+  const int n_lo = max(0, t0 * HOP - 400), n_hi = min(L, (t1 - 1) * HOP + 400);
+  const int nseg = n_hi - n_lo;
+  for (int j = tid; j <= HALF; j += 256) {
+    float sn, cs;
+    sincospif((float)j * (1.0f / 512.0f), &sn, &cs);
+    W[j] = make_float2(cs, -sn);
+  }
+  for (int j = tid; j < WLEN; j += 256) win[j] = 0.5f - 0.5f * cospif(2.0f * (float)j / (float)WLEN);   // hann(800), periodic
+  for (int j = tid; j < nseg; j += 256) seg[j] = 0.f;
+  __syncthreads();
+
+  // ---- inverse transforms of frames i_lo..i_hi, overlap-added into seg (four phases: i mod 4) --------------------------
+  const int i_lo = max(0, floordiv(n_lo - 400, HOP) + 1), i_hi = min(T - 1, (n_hi - 1 + 400) / HOP);
+  float2* mybuf = wb + wave * WBUF;
+  const float2* Sin = reinterpret_cast<const float2*>(spec_in) + (int64_t)u * p.T_max * NB;
+#pragma unroll 1
+  for (int ph = 0; ph < 4; ++ph) {
+    const int first = i_lo + ((ph - i_lo) & 3);
+#pragma unroll 1
+    for (int i = first + 4 * wave; i <= i_hi; i += 4 * NWAVE) {
+      const float2* X = Sin + (int64_t)i * NB;
+      float2 v[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int k = lane + 64 * r;
+        float2 a = X[k], b = X[HALF - k];
+        if (k == 0) { a.y = 0.f; b.y = 0.f; }                                // irfft ignores the imaginary parts of DC / Nyquist
+        b.y = -b.y;
+        const float2 s = cadd(a, b), d = csub(a, b);
+        const float2 w = W[k];
+        const float2 t = cmul(d, make_float2(w.x, -w.y));                    // d * exp(+2 pi i k / 1024)
+        v[r] = make_float2(s.x - t.y, s.y + t.x);                            // Z = s + i t
+      }
+      fft512<true>(v, mybuf, W, lane);
+      const int nb = i * HOP - HALF;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int k = 2 * (lane + 64 * r);
+        const int n0 = nb + k;
+        if (k >= WOFF && k < WOFF + WLEN && n0 >= n_lo && n0 < n_hi) seg[n0 - n_lo] += v[r].x * (1.0f / 1024.0f) * win[k - WOFF];
+        if (k + 1 >= WOFF && k + 1 < WOFF + WLEN && n0 + 1 >= n_lo && n0 + 1 < n_hi)
+          seg[n0 + 1 - n_lo] += v[r].y * (1.0f / 1024.0f) * win[k + 1 - WOFF];
+      }
+    }
+    __syncthreads();
+  }
+  // ---- window-sum-square normalisation (librosa.istft) --------------------------------------------------------------------
+  for (int j = tid; j < nseg; j += 256) {
+    const int pos = n_lo + j + HALF;
+    const int ia = max(0, (pos - (WOFF + WLEN - 1) + HOP - 1) / HOP), ib = min(T - 1, (pos - WOFF) / HOP);
+    float wss = 0.f;
+    for (int i = ia; i <= ib; ++i) { const float w = win[pos - i * HOP - WOFF]; wss += w * w; }
+    float val = seg[j];
+    if (wss > 1.17549435e-38f) val /= wss;
+    seg[j] = val;
+  }
+  __syncthreads();
+
+  if (spec_out == nullptr) {                                                  // final pass: the waveform is the result
+    const int own_lo = tile == 0 ? 0 : t0 * HOP - 100, own_hi = tile == nt - 1 ? L : t1 * HOP - 100;
+    float* wav = p.wav + (int64_t)u * p.wav_ld;
+    for (int n = own_lo + tid; n < own_hi; n += 256) wav[n] = seg[n - n_lo];
+    return;
+  }
+
+  // ---- forward transforms of the tile's own frames + projection onto the given magnitudes -----------------------------------
+  const float* Mu = p.mag + (int64_t)u * p.T_max * NB;
+  float2* Sout = reinterpret_cast<float2*>(spec_out) + (int64_t)u * p.T_max * NB;
+#pragma unroll 1
+  for (int t = t0 + wave; t < t1; t += NWAVE) {
+    float2 v[8];
+    const int nb = t * HOP - HALF;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int k = 2 * (lane + 64 * r);
+      float x0 = 0.f, x1 = 0.f;
+      if (k >= WOFF && k < WOFF + WLEN) {                                     // k even, WOFF even: k + 1 is inside too
+        int a = nb + k, b = nb + k + 1;
+        if (a < 0) a = -a;
+        if (a >= L) a = 2 * (L - 1) - a;
+        if (b < 0) b = -b;
+        if (b >= L) b = 2 * (L - 1) - b;
+        a = min(max(a, n_lo), n_hi - 1); b = min(max(b, n_lo), n_hi - 1);     // (no-ops: the segment covers the reflections)
+        x0 = seg[a - n_lo] * win[k - WOFF];
+        x1 = seg[b - n_lo] * win[k + 1 - WOFF];
+      }
+      v[r] = make_float2(x0, x1);
+    }
+    fft512<false>(v, mybuf, W, lane);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) mybuf[padi(lane + 64 * r)] = v[r];
+    wave_lds_sync();
+    const float* M = Mu + (int64_t)t * NB;
+    float2* So = Sout + (int64_t)t * NB;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int k = lane + 64 * r;
+      const float2 a = v[r];
+      float2 b = mybuf[padi((HALF - k) & (HALF - 1))];
+      b.y = -b.y;
+      const float2 s = cadd(a, b), d = csub(a, b);
+      const float2 tt = cmul(d, W[k]);
+      const float2 e = make_float2(0.5f * (s.x + tt.y), 0.5f * (s.y - tt.x));   // E[k] = (a+b)/2 - (i/2) W^k (a-b)
+      const float mag = sqrtf(e.x * e.x + e.y * e.y);
+      const float sc = M[k] / fmaxf(1e-8f, mag);                              // X = S * E / max(1e-8, |E|)   (convert.py:50)
+      So[k] = make_float2(e.x * sc, e.y * sc);
+    }
+    if (lane == 0) {                                                          // Nyquist bin: E[512] = Re Z0 - Im Z0
+      const float2 z0 = mybuf[0];
+      const float e = z0.x - z0.y;
+      const float sc = M[HALF] / fmaxf(1e-8f, fabsf(e));
+      So[HALF] = make_float2(e * sc, 0.f);
+    }
+    wave_lds_sync();
+  }
+}
+
+// signal.lfilter([1], [1, -coef], wav) (convert.py:60), float64 recursion y[n] = x[n] + coef y[n-1]: one workgroup per
+// utterance, every thread a contiguous chunk; pass 1 finds each chunk's end value from a zero state, a serial scan over the
+// 256 chunk ends gives every chunk its true carry-in, pass 2 replays the chunk from it (same operation order as the
+// sequential filter inside a chunk; the carry-in differs from the sequential value at the 1e-16 level).
+__global__ __launch_bounds__(256) void gl_deemph_scan_kernel(float* wav, int64_t wav_ld, const int32_t* lengths, float coef) {
+  __shared__ double e_end[256];
+  __shared__ double carry[256];
+  const int u = blockIdx.x, tid = threadIdx.x;
+  const int L = HOP * (lengths[u] - 1);
+  if (L <= 0) return;
+  float* w = wav + (int64_t)u * wav_ld;
+  const int C = (L + 255) / 256;
+  const int lo = min(L, tid * C), hi = min(L, lo + C);
+  const double a = (double)coef;
+  double acc = 0.0;
+  for (int i = lo; i < hi; ++i) acc = (double)w[i] + a * acc;
+  e_end[tid] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    double aC = 1.0;
+    for (int i = 0; i < C; ++i) aC *= a;
+    double c = 0.0;
+    for (int j = 0; j < 256; ++j) {
+      carry[j] = c;                                                          // y[j*C - 1]
+      const int n = min(L, (j + 1) * C) - min(L, j * C);
+      c = (n == C) ? e_end[j] + aC * c : (n > 0 ? e_end[j] + pow(a, (double)n) * c : c);
+    }
+  }
+  __syncthreads();
+  acc = carry[tid];
+  for (int i = lo; i < hi; ++i) { acc = (double)w[i] + a * acc; w[i] = (float)acc; }
+}
+
+size_t gl_lds_bytes(int F) { return (size_t)WTAB * 8 + WLEN * 4 + (size_t)NWAVE * WBUF * 8 + ((size_t)(F - 1) * HOP + 800) * 4; }
+
+int gl_launch(const ZsGlIter* p, const float* in, float* out, hipStream_t s) {
+  const int F = p->tile_frames > 0 ? p->tile_frames : 26;
+  dim3 grid((unsigned)((p->T_max + F - 1) / F), (unsigned)p->n_utt);
+  hipLaunchKernelGGL(gl_iter_kernel, grid, dim3(256), gl_lds_bytes(F), s, *p, in, out, F);
+  return zs_check_launch("zs_gl_iter");
+}
+
+int gl_check(const ZsGlIter* p, const char* what) {
+  ZS_REQUIRE(p && p->mag && p->lengths && p->n_utt > 0 && p->T_max >= 4, "%s: bad args", what);
+  ZS_REQUIRE(p->tile_frames == 0 || (p->tile_frames >= 4 && p->tile_frames <= 42), "%s: tile_frames must be in [4, 42]", what);
+  return ZS_OK;
+}
+
+}  // namespace
+
+extern "C" int zs_gl_iter(const ZsGlIter* p, void* stream) {
+  int rc = gl_check(p, "zs_gl_iter");
+  if (rc) return rc;
+  ZS_REQUIRE(p->spec_in && p->spec_in != p->spec_out, "zs_gl_iter: spec_in must be given and differ from spec_out");
+  ZS_REQUIRE(p->spec_out || (p->wav && p->wav_ld >= (int64_t)HOP * (p->T_max - 1)), "zs_gl_iter: final pass needs wav (wav_ld >= 200*(T_max-1))");
+  return gl_launch(p, p->spec_in, p->spec_out, (hipStream_t)stream);
+}
+
+extern "C" int zs_griffin_lim(const ZsGlIter* p, float* spec_a, float* spec_b, int32_t n_iter, void* stream) {
+  int rc = gl_check(p, "zs_griffin_lim");
+  if (rc) return rc;
+  ZS_REQUIRE(spec_a && spec_b && spec_a != spec_b && n_iter >= 0, "zs_griffin_lim: two distinct spectrogram buffers are required");
+  ZS_REQUIRE(p->wav && p->wav_ld >= (int64_t)HOP * (p->T_max - 1), "zs_griffin_lim: wav_ld too small");
+  float* cur = spec_a;
+  float* nxt = spec_b;
+  for (int it = 0; it < n_iter; ++it) {
+    rc = gl_launch(p, cur, nxt, (hipStream_t)stream);
+    if (rc) return rc;
+    float* t = cur; cur = nxt; nxt = t;
+  }
+  return gl_launch(p, cur, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int zs_gl_deemphasis(float* wav, int64_t wav_ld, const int32_t* lengths, int32_t n_utt, float coef, void* stream) {
+  ZS_REQUIRE(wav && lengths && n_utt > 0, "zs_gl_deemphasis: bad args");
+  hipLaunchKernelGGL(gl_deemph_scan_kernel, dim3((unsigned)n_utt), dim3(256), 0, (hipStream_t)stream, wav, wav_ld, lengths, coef);
+  return zs_check_launch("zs_gl_deemphasis");
+}

@@ -179,15 +179,6 @@ __global__ void gl_denorm_kernel(const float* in, float* out, int64_t n) {
   }
 }
 
-__global__ void gl_deemph_kernel(float* wav, int64_t wav_ld, const int32_t* lengths, int n_utt, float coef) {
-  const int u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= n_utt) return;
-  const int L = HOP * (lengths[u] - 1);
-  float* w = wav + (int64_t)u * wav_ld;
-  double acc = 0.0;                                                 // lfilter([1],[1,-0.97]) runs in float64
-  for (int i = 0; i < L; ++i) { acc = (double)w[i] + (double)coef * acc; w[i] = (float)acc; }
-}
-
 }  // namespace
 
 extern "C" int zs_gl_istft(const ZsGlIstft* p, void* stream) {
@@ -227,10 +218,4 @@ extern "C" int zs_gl_denormalize(const float* mag_norm, float* mag_amp, int64_t 
   int64_t nb = (n + 255) / 256; if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(gl_denorm_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, mag_norm, mag_amp, n);
   return zs_check_launch("zs_gl_denormalize");
-}
-
-extern "C" int zs_gl_deemphasis(float* wav, int64_t wav_ld, const int32_t* lengths, int32_t n_utt, float coef, void* stream) {
-  ZS_REQUIRE(wav && lengths && n_utt > 0, "zs_gl_deemphasis: bad args");
-  hipLaunchKernelGGL(gl_deemph_kernel, dim3((n_utt + 63) / 64), dim3(64), 0, (hipStream_t)stream, wav, wav_ld, lengths, (int)n_utt, coef);
-  return zs_check_launch("zs_gl_deemphasis");
 }
