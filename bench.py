@@ -39,6 +39,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='issue every launch from the host instead of replaying hipGraphs')
+    ap.add_argument('--mode', choices=['train_ae', 'resynth'], default='train_ae',
+                    help='resynth: BASELINE config 4 (test_encode + Griffin-Lim resynthesis of 64 utterances) instead of the headline train_ae step')
+    ap.add_argument('--utts', type=int, default=64)
     ap.add_argument('--host-input', action='store_true', help='copy the batch from pinned host memory every step (PCIe-inclusive rate; never the headline value)')
     return ap.parse_args()
 
@@ -201,10 +204,128 @@ def spawn_ranks(args):
     return rc
 
 
+def resynth_main(args):
+    """BASELINE config 4: test_encode + convert.py Griffin-Lim resynthesis of 64 utterances of U{200..700} frames on one MI355X
+    (full-size english model, random weights, bf16 network, fp32 vocoder, n_iter = 300).  A "step" = the whole batch once:
+    fragmenting, Encoder + Decoder over every fragment, de-normalisation, 300 Griffin-Lim iterations, de-emphasis, trim.
+    Inputs resident on the host as the reference's loader hands them over (numpy spectrograms): the utterances/s here INCLUDE the
+    host-side fragment logic and the H2D / D2H copies.  Multi-GPU: replicas over a sharded utterance list, no collective.
+    roofline: the dominant kernel gl_iter_kernel (one fused Griffin-Lim iteration): achieved = algorithmic FLOPs of the real
+    1024-point transforms (2 per frame and iteration, 2.5 N log2 N each: SURVEY 8(d)'s ~25 kFLOP per transform) / HIP-event time
+    of the zs_griffin_lim loop on the launch stream, against the fp32 vector peak (157.3 TFLOP/s): FFT / latency-bound."""
+    import tempfile
+    import numpy as np
+    import zs_amd  # noqa: F401
+    from zs_amd import convert as cv, layers, parallel
+    from zs_amd.hps import hp, make_hps
+    from zs_amd.trainer import Trainer
+    rank, world, local = parallel.init_from_env(os.environ.get('ZS_DIST_BACKEND', 'nccl'))
+    if world != args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE is %d\n' % (args.gpus, world))
+        sys.exit(2)
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    os.environ['LOCAL_RANK'] = str(local)
+    torch.manual_seed(1)
+    hps = make_hps(enc_size=1024, emb_size=1024, n_speakers=102)
+    tr = Trainer(hps, None, 'targeted_residual', 'multilabel_binary', log_dir=tempfile.mkdtemp(), dtype=args.dtype, device=dev)
+    rng = np.random.RandomState(0)
+    lens_all = rng.randint(200, 701, size=args.utts * world)
+    lo, hi = parallel.shard_range(len(lens_all), rank, world)
+    lens = lens_all[lo:hi]
+    specs = [np.clip(rng.rand(int(n), 513).astype(np.float32), 1e-8, 1) for n in lens]
+    spk = [int(rng.randint(0, 102)) for _ in specs]
+    n_iter = hp.n_iter
+    gl_ms = []
+
+    def run(timed):
+        encs, decs = cv.encode_batch(specs, tr, 128, decode_speakers=spk)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        orig = cv.griffin_lim_batch
+
+        def timed_gl(*a, **kw):
+            s.record()
+            r = orig(*a, **kw)
+            e.record()
+            return r
+        cv.griffin_lim_batch = timed_gl
+        try:
+            wavs = cv.spectrogram2wav_batch(decs, n_iter=n_iter, do_trim=True)
+        finally:
+            cv.griffin_lim_batch = orig
+        if timed:
+            torch.cuda.synchronize()
+            gl_ms.append(s.elapsed_time(e))
+        return encs, decs, wavs
+
+    for _ in range(max(1, args.warmup)):
+        run(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        encs, decs, wavs = run(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    layers.check_status(dev)
+    t1 = time.perf_counter()
+    cv.encode_batch(specs, tr, 128, decode_speakers=spk)
+    torch.cuda.synchronize()
+    dt_enc = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+        return
+    out_frames = int(sum(d.shape[0] for d in decs))
+    n_utt = len(lens_all)
+    value = n_utt * args.steps / dt
+    gl = sum(gl_ms) / len(gl_ms) * 1e-3
+    fl = out_frames * (2 * n_iter + 1) * 2.5 * 1024 * 10          # per rank-0 shard
+    out = {'metric': 'utterances/sec (test_encode + Griffin-Lim resynthesis, 64 utterances of 200..700 frames, n_iter=300)',
+           'value': value, 'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+           'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+           'dtype': 'f32 (vocoder) / %s (network)' % args.dtype, 'data': 'synthetic',
+           'config': {'workload': 'BASELINE config 4: encode + decode (english hps, enc_size=1024, emb_size=1024) + spectrogram2wav '
+                                  '(Griffin-Lim n_iter=%d, de-emphasis, trim) of %d utterances of U{200..700} frames per GPU, host '
+                                  'fragmenting and copies included' % (n_iter, len(lens)), 'parallelism': 'replicas%d' % world},
+           'frames_per_s': float(sum(lens_all)) * args.steps / dt, 'encode_decode_ms': 1e3 * dt_enc, 'griffin_lim_ms': 1e3 * gl,
+           'roofline': {'bound': 'fft-latency (fp32 vector peak as the ceiling)', 'achieved': fl / gl / 1e12, 'peak': 157.3, 'unit': 'TFLOP/s',
+                        'frac': fl / gl / 1e12 / 157.3, 'traffic': None,
+                        'kernel': 'gl_iter_kernel (one fused Griffin-Lim iteration per launch, %d launches per batch)' % (n_iter + 1),
+                        'avg_launch_ms': 1e3 * gl / (n_iter + 1), 'algorithmic_flop_per_launch': fl / (2 * n_iter + 1) * 2}}
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+        import zs_oracle as O      # CPU baseline beside the measurement only
+        cores = cpu_share()
+        torch.set_num_threads(cores)
+        d = np.asarray(decs[int(np.argmin([abs(x.shape[0] - 376) for x in decs]))], dtype=np.float32)
+        t0 = time.perf_counter()
+        O.spectrogram2wav(d, n_iter=n_iter)
+        dc = time.perf_counter() - t0
+        out['cpu_baseline'] = {'value': 1.0 / dc, 'unit': 'utterances/s', 'cores': cores, 'kind': 'port',
+                               'sample': 'oracle spectrogram2wav (Griffin-Lim n_iter=%d, numpy FFT) of ONE %d-frame utterance: %.2f s; the '
+                                         'network forward is not included (the vocoder is >95 %% of the CPU path)' % (n_iter, d.shape[0], dc)}
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args))
+    if args.mode == 'resynth':
+        return resynth_main(args)
     import zs_amd  # noqa: F401
     from zs_amd import parallel
     from zs_amd.model import Decoder, Encoder

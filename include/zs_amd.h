@@ -372,7 +372,7 @@ typedef struct {
   const float* spec_in; float* spec_out;
   const float* mag; const int32_t* lengths; int32_t n_utt, T_max;
   float* wav; int64_t wav_ld;
-  int32_t tile_frames;           /* STFT frames per workgroup tile (4..42), 0 = default 26 */
+  int32_t tile_frames;           /* STFT frames per workgroup tile (4..42), 0 = default 10 */
 } ZsGlIter;
 int zs_gl_iter(const ZsGlIter* p, void* stream);
 int zs_griffin_lim(const ZsGlIter* p, float* spec_a, float* spec_b, int32_t n_iter, void* stream);

@@ -5,8 +5,7 @@
 // gfx950 design
 //  * A workgroup (4 waves) owns a tile of F consecutive STFT frames [t0, t1) of one utterance.  With the hann(800) window
 //    centred in the 1024-sample frame a waveform sample is touched by exactly 4 frames and an output frame depends on the
-//    input frames t-3 .. t+3: the tile inverse-transforms F + 6 frames (3 halo frames per side, 23 % extra inverse work at
-//    F = 26), overlap-adds them into an LDS segment of (F-1)*200 + 800 samples, divides by the window-sum-square, and
+//    input frames t-3 .. t+3: the tile inverse-transforms F + 6 frames (3 halo frames per side), overlap-adds them into an LDS segment of (F-1)*200 + 800 samples, divides by the window-sum-square, and
 //    transforms its own F frames forward.  HBM / Infinity-Cache traffic per frame and iteration: the spectrogram once in
 //    and once out (2 x 4.1 KB) + the halo re-reads -- against ~25 KB for the unfused frames -> overlap-add -> frames chain.
 //  * Frames whose indices are equal mod 4 never overlap (4 * hop = 800 = window length), so the overlap-add runs in four
@@ -16,9 +15,15 @@
 //    two wave-private LDS exchanges between them (skewed by i + i/8 -> every ds access pattern of the three passes is
 //    bank-conflict free for a half-wave), no workgroup barrier inside the transform.  Twiddles: one LDS table of the
 //    1024th roots of unity per workgroup (the 512th and 64th roots are strided views), powers w^2..w^7 by multiplication.
-//  * Twiddle table, window and segment share 49 KB of LDS at F = 26 -> three workgroups (12 waves) per CU.
+//  * Twiddle table, window, exchange buffers and segment take 36 KB of LDS at the default F = 10 -> four workgroups (16 waves)
+//    per CU.  Small tiles win although they transform 60 % more inverse frames (F = 10: 43 ms for 300 iterations of 64 utterances
+//    of 200..700 frames, F = 26: 51 ms, F = 42: 67 ms): the kernel is bound by the latency of its spectrum loads and of the four
+//    overlap-add phases, which more workgroups in flight hide; the spectrum of a wave's next frame is prefetched under the
+//    current transform.
 // zs_griffin_lim runs the whole loop (n_iter launches ping-ponging two spectrogram buffers + the final inverse pass) from
 // one C call.  The older one-transform-per-workgroup kernels (zs_vocoder.hip) remain as the variant the tests compare with.
+#include <atomic>
+
 #include "zs_common.h"
 
 namespace {
@@ -27,6 +32,7 @@ constexpr int NB = 513, HOP = 200, WLEN = 800, WOFF = 112, HALF = 512;
 constexpr int WBUF = 576;      // complex slots of a wave's exchange buffer: 512 + 512/8 skew
 constexpr int NWAVE = 4;
 constexpr int WTAB = 520;      // 513 roots, padded
+constexpr int GL_TILE_DEFAULT = 10;   // measured on 64 utterances of 200..700 frames: 10 -> 43 ms, 26 -> 51 ms, 42 -> 67 ms per 300 iterations
 
 __device__ __forceinline__ int padi(int i) { return i + (i >> 3); }
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -101,8 +107,24 @@ __device__ __forceinline__ void fft512(float2 (&v)[8], float2* buf, const float2
   dft8<INV>(v);
 }
 
+// exp(-2 pi i k / 1024), k = 0..512, and hann(800) (periodic): filled by gl_tables_kernel at the head of every zs_griffin_lim /
+// zs_gl_iter call (stream-ordered before the kernels that read it; concurrent calls write identical values)
+__device__ float2 g_gl_roots[WTAB];
+__device__ float g_gl_window[WLEN];
+
+__global__ void gl_tables_kernel() {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j <= HALF) {
+    float sn, cs;
+    sincospif((float)j * (1.0f / 512.0f), &sn, &cs);
+    g_gl_roots[j] = make_float2(cs, -sn);
+  }
+  if (j < WLEN) g_gl_window[j] = 0.5f - 0.5f * cospif(2.0f * (float)j / (float)WLEN);
+}
+
 __device__ __forceinline__ int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
+template <bool PF>   // PF: prefetch the spectrum of a wave's next inverse frame under the current transform (+32 VGPRs)
 __global__ __launch_bounds__(256) void gl_iter_kernel(const ZsGlIter p, const float* spec_in, float* spec_out, int F) {
   extern __shared__ __align__(16) unsigned char gl_smem[];
   float2* W = reinterpret_cast<float2*>(gl_smem);
@@ -119,12 +141,8 @@ __global__ __launch_bounds__(256) void gl_iter_kernel(const ZsGlIter p, const fl
   const int L = HOP * (T - 1);
   const int n_lo = max(0, t0 * HOP - 400), n_hi = min(L, (t1 - 1) * HOP + 400);
   const int nseg = n_hi - n_lo;
-  for (int j = tid; j <= HALF; j += 256) {
-    float sn, cs;
-    sincospif((float)j * (1.0f / 512.0f), &sn, &cs);
-    W[j] = make_float2(cs, -sn);
-  }
-  for (int j = tid; j < WLEN; j += 256) win[j] = 0.5f - 0.5f * cospif(2.0f * (float)j / (float)WLEN);   // hann(800), periodic
+  for (int j = tid; j <= HALF; j += 256) W[j] = g_gl_roots[j];
+  for (int j = tid; j < WLEN; j += 256) win[j] = g_gl_window[j];                                          // hann(800), periodic
   for (int j = tid; j < nseg; j += 256) seg[j] = 0.f;
   __syncthreads();
 
@@ -135,20 +153,37 @@ __global__ __launch_bounds__(256) void gl_iter_kernel(const ZsGlIter p, const fl
 #pragma unroll 1
   for (int ph = 0; ph < 4; ++ph) {
     const int first = i_lo + ((ph - i_lo) & 3);
-#pragma unroll 1
-    for (int i = first + 4 * wave; i <= i_hi; i += 4 * NWAVE) {
+    // software pipeline: the spectrum of this wave's next frame is fetched while the current one is transformed
+    float2 xa[8], xb[8];
+    int i = first + 4 * wave;
+    if (PF && i <= i_hi) {
       const float2* X = Sin + (int64_t)i * NB;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { xa[r] = X[lane + 64 * r]; xb[r] = X[HALF - lane - 64 * r]; }
+    }
+#pragma unroll 1
+    for (; i <= i_hi; i += 4 * NWAVE) {
       float2 v[8];
+      if (!PF) {
+        const float2* X = Sin + (int64_t)i * NB;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { xa[r] = X[lane + 64 * r]; xb[r] = X[HALF - lane - 64 * r]; }
+      }
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int k = lane + 64 * r;
-        float2 a = X[k], b = X[HALF - k];
+        float2 a = xa[r], b = xb[r];
         if (k == 0) { a.y = 0.f; b.y = 0.f; }                                // irfft ignores the imaginary parts of DC / Nyquist
         b.y = -b.y;
         const float2 s = cadd(a, b), d = csub(a, b);
         const float2 w = W[k];
         const float2 t = cmul(d, make_float2(w.x, -w.y));                    // d * exp(+2 pi i k / 1024)
         v[r] = make_float2(s.x - t.y, s.y + t.x);                            // Z = s + i t
+      }
+      if (PF && i + 4 * NWAVE <= i_hi) {
+        const float2* X = Sin + (int64_t)(i + 4 * NWAVE) * NB;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { xa[r] = X[lane + 64 * r]; xb[r] = X[HALF - lane - 64 * r]; }
       }
       fft512<true>(v, mybuf, W, lane);
       const int nb = i * HOP - HALF;
@@ -205,11 +240,15 @@ __global__ __launch_bounds__(256) void gl_iter_kernel(const ZsGlIter p, const fl
       }
       v[r] = make_float2(x0, x1);
     }
+    const float* M = Mu + (int64_t)t * NB;
+    float mg[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) mg[r] = M[lane + 64 * r];                     // in flight under the transform
+    const float mg_ny = M[HALF];
     fft512<false>(v, mybuf, W, lane);
 #pragma unroll
     for (int r = 0; r < 8; ++r) mybuf[padi(lane + 64 * r)] = v[r];
     wave_lds_sync();
-    const float* M = Mu + (int64_t)t * NB;
     float2* So = Sout + (int64_t)t * NB;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -221,13 +260,13 @@ __global__ __launch_bounds__(256) void gl_iter_kernel(const ZsGlIter p, const fl
       const float2 tt = cmul(d, W[k]);
       const float2 e = make_float2(0.5f * (s.x + tt.y), 0.5f * (s.y - tt.x));   // E[k] = (a+b)/2 - (i/2) W^k (a-b)
       const float mag = sqrtf(e.x * e.x + e.y * e.y);
-      const float sc = M[k] / fmaxf(1e-8f, mag);                              // X = S * E / max(1e-8, |E|)   (convert.py:50)
+      const float sc = mg[r] / fmaxf(1e-8f, mag);                              // X = S * E / max(1e-8, |E|)   (convert.py:50)
       So[k] = make_float2(e.x * sc, e.y * sc);
     }
     if (lane == 0) {                                                          // Nyquist bin: E[512] = Re Z0 - Im Z0
       const float2 z0 = mybuf[0];
       const float e = z0.x - z0.y;
-      const float sc = M[HALF] / fmaxf(1e-8f, fabsf(e));
+      const float sc = mg_ny / fmaxf(1e-8f, fabsf(e));
       So[HALF] = make_float2(e * sc, 0.f);
     }
     wave_lds_sync();
@@ -267,12 +306,15 @@ __global__ __launch_bounds__(256) void gl_deemph_scan_kernel(float* wav, int64_t
   for (int i = lo; i < hi; ++i) { acc = (double)w[i] + a * acc; w[i] = (float)acc; }
 }
 
+std::atomic<int> g_gl_prefetch{0};
+
 size_t gl_lds_bytes(int F) { return (size_t)WTAB * 8 + WLEN * 4 + (size_t)NWAVE * WBUF * 8 + ((size_t)(F - 1) * HOP + 800) * 4; }
 
 int gl_launch(const ZsGlIter* p, const float* in, float* out, hipStream_t s) {
-  const int F = p->tile_frames > 0 ? p->tile_frames : 26;
+  const int F = p->tile_frames > 0 ? p->tile_frames : GL_TILE_DEFAULT;
   dim3 grid((unsigned)((p->T_max + F - 1) / F), (unsigned)p->n_utt);
-  hipLaunchKernelGGL(gl_iter_kernel, grid, dim3(256), gl_lds_bytes(F), s, *p, in, out, F);
+  if (g_gl_prefetch.load(std::memory_order_relaxed)) hipLaunchKernelGGL(gl_iter_kernel<true>, grid, dim3(256), gl_lds_bytes(F), s, *p, in, out, F);
+  else hipLaunchKernelGGL(gl_iter_kernel<false>, grid, dim3(256), gl_lds_bytes(F), s, *p, in, out, F);
   return zs_check_launch("zs_gl_iter");
 }
 
@@ -284,9 +326,13 @@ int gl_check(const ZsGlIter* p, const char* what) {
 
 }  // namespace
 
+// "gl_prefetch" knob of zs_set_option
+int zs_gl_prefetch_option(int value) { return g_gl_prefetch.exchange(value ? 1 : 0, std::memory_order_relaxed); }
+
 extern "C" int zs_gl_iter(const ZsGlIter* p, void* stream) {
   int rc = gl_check(p, "zs_gl_iter");
   if (rc) return rc;
+  hipLaunchKernelGGL(gl_tables_kernel, dim3(4), dim3(256), 0, (hipStream_t)stream);
   ZS_REQUIRE(p->spec_in && p->spec_in != p->spec_out, "zs_gl_iter: spec_in must be given and differ from spec_out");
   ZS_REQUIRE(p->spec_out || (p->wav && p->wav_ld >= (int64_t)HOP * (p->T_max - 1)), "zs_gl_iter: final pass needs wav (wav_ld >= 200*(T_max-1))");
   return gl_launch(p, p->spec_in, p->spec_out, (hipStream_t)stream);
@@ -297,6 +343,7 @@ extern "C" int zs_griffin_lim(const ZsGlIter* p, float* spec_a, float* spec_b, i
   if (rc) return rc;
   ZS_REQUIRE(spec_a && spec_b && spec_a != spec_b && n_iter >= 0, "zs_griffin_lim: two distinct spectrogram buffers are required");
   ZS_REQUIRE(p->wav && p->wav_ld >= (int64_t)HOP * (p->T_max - 1), "zs_griffin_lim: wav_ld too small");
+  hipLaunchKernelGGL(gl_tables_kernel, dim3(4), dim3(256), 0, (hipStream_t)stream);
   float* cur = spec_a;
   float* nxt = spec_b;
   for (int it = 0; it < n_iter; ++it) {
