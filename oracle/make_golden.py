@@ -255,6 +255,101 @@ def gen_vocoder():
     print('  wrote %d wav sample counts' % len(counts))
 
 
+class _MaskDrop(torch.nn.Module):
+    """Stands in for one nn.Dropout2d of the reference module so that the keep masks are known: y = x * keep / (1 - p)."""
+
+    def __init__(self, p):
+        super(_MaskDrop, self).__init__()
+        self.p, self.queue = p, []
+
+    def forward(self, x):
+        m = self.queue.pop(0)
+        return x * m[:, :, None, None] / (1.0 - self.p)
+
+
+def gen_stage2():
+    """Stage 2 (--train_p / --train_tgat): the reference's PatchDiscriminator, its WGAN-GP penalty
+    (utils.calculate_gradients_penalty, double backward) and the patchGAN losses of trainer.py:488-494 / 528-533 on B = 2
+    segments.  The 10.9 M discriminator weights are regenerated from a seed (O.synthetic_patch_sd); the fixture holds inputs,
+    Dropout2d keep masks, losses, logits, a strided sample + the norm of every parameter gradient, and dLoss_G/dx_gen."""
+    import types
+    sys.modules.setdefault('tensorboardX', types.SimpleNamespace(SummaryWriter=object))
+    from model.model import PatchDiscriminator                      # the reference
+    from utils import calculate_gradients_penalty                    # the reference
+    ns, seg_len, n_class, dp, B = 0.01, 128, 2, 0.1, 2
+    hp = dict(ns=ns, seg_len=seg_len, dp=dp, training=True, beta_dis=1.0, beta_clf=1.0, beta_gen=1.0, lambda_=10.0)
+    sd = O.synthetic_patch_sd(n_class, seed=7)
+    D = PatchDiscriminator(n_class=n_class, ns=ns, dp=dp, seg_len=seg_len)
+    D.load_state_dict(sd)
+    D.train()
+    drops = [_MaskDrop(dp) for _ in range(6)]
+    for i, d in enumerate(drops):
+        setattr(D, 'drop%d' % (i + 1), d)
+    g = torch.Generator().manual_seed(21)
+    x_t = torch.rand(B, 513, seg_len, generator=g)
+    x_dec = torch.rand(B, 513, seg_len, generator=g).requires_grad_(True)     # as in training: x_dec comes out of gen_step (the
+    c = torch.randint(0, n_class, (B,), generator=g)                           # reference's penalty differentiates w.r.t. it)
+    chans = [64, 128, 256, 512, 512, 32]
+    masks = [[(torch.rand(B, ch, generator=g) >= dp).float() for ch in chans] for _ in range(4)]      # real, fake, interpolate, G-step
+
+    def feed(m):
+        for d, mk in zip(drops, m):
+            d.queue.append(mk)
+
+    # ---- D step (trainer.py:480-494) on the reference modules
+    feed(masks[0]); D_real, real_logits = D(x_t, classify=True)
+    feed(masks[1]); D_fake, fake_logits = D(x_dec, classify=True)
+    w_dis = torch.mean(D_real - D_fake)
+    feed(masks[2])
+    torch.manual_seed(99)
+    gp = calculate_gradients_penalty(D, x_t, x_dec)
+    torch.manual_seed(99)
+    alpha = torch.rand(B)
+    loss_clf = torch.nn.CrossEntropyLoss()(real_logits, c)
+    loss = -hp['beta_dis'] * w_dis + hp['beta_clf'] * loss_clf + hp['lambda_'] * gp
+    D.zero_grad()
+    loss.backward()
+    gref = {k: p.grad.detach().clone() for k, p in D.named_parameters()}
+    # ---- the oracle on the same inputs
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    x_dec = x_dec.detach()
+    o_loss, o_w, o_clf, o_gp, o_logits = O.patch_d_loss(p, x_t, x_dec, c, alpha, hp, masks=masks[:3])
+    o_loss.backward()
+    check('stage2 D_real', O.patch_discriminator_forward(sd, x_t, ns, seg_len, dp=dp, drop_masks=masks[0]), D_real.detach(), 2e-5)
+    check('stage2 real logits', o_logits.detach(), real_logits.detach(), 2e-5)
+    check('stage2 w_dis', o_w.detach(), w_dis.detach(), 2e-5)
+    check('stage2 gp', o_gp.detach(), gp.detach(), 2e-5)
+    check('stage2 D loss', o_loss.detach(), loss.detach(), 2e-5)
+    for k in gref:
+        check('stage2 D grad ' + k, p[k].grad, gref[k], 1e-7 + 2e-4 * float(gref[k].abs().max()))
+    out = dict(x_t=x_t.numpy(), x_dec=x_dec.numpy(), c=c.numpy(), alpha=alpha.numpy(), D_real=D_real.detach().numpy(),
+               D_fake=D_fake.detach().numpy(), real_logits=real_logits.detach().numpy(), w_dis=np.float32(w_dis.item()),
+               gp=np.float32(gp.item()), loss_clf=np.float32(loss_clf.item()), loss_d=np.float32(loss.item()))
+    for pi, ms in enumerate(masks):
+        for li, mk in enumerate(ms):
+            out['mask.%d.%d' % (pi, li)] = mk.numpy().astype(np.uint8)
+    for k, v in gref.items():
+        flat = v.reshape(-1)
+        out['gD.norm.' + k] = np.float32(flat.double().norm().item())
+        out['gD.sample.' + k] = flat[::max(1, flat.numel() // 512)][:512].numpy().copy()
+    # ---- G step (trainer.py:524-533): gradient of the generator loss w.r.t. the generated spectrogram
+    x_gen = x_dec.clone().requires_grad_(True)
+    feed(masks[3]); D_f, f_logits = D(x_gen, classify=True)
+    loss_adv = -torch.mean(D_f)
+    loss_g = hp['beta_clf'] * torch.nn.CrossEntropyLoss()(f_logits, c) + hp['beta_gen'] * loss_adv
+    dx, = torch.autograd.grad(loss_g, x_gen)
+    xo = x_dec.clone().requires_grad_(True)
+    o_lg, o_adv, o_c, o_fl = O.patch_g_loss(sd, xo, c, hp, masks=masks[3])
+    odx, = torch.autograd.grad(o_lg, xo)
+    check('stage2 G loss', o_lg.detach(), loss_g.detach(), 2e-5)
+    check('stage2 dLoss_G/dx_gen', odx, dx, 1e-8 + 2e-4 * float(dx.abs().max()))
+    out.update(loss_g=np.float32(loss_g.item()), loss_adv=np.float32(loss_adv.item()), fake_logits=f_logits.detach().numpy(),
+               dx_gen=dx.numpy())
+    out['meta'] = np.array(json.dumps(dict(ns=ns, seg_len=seg_len, n_class=n_class, dp=dp, B=B, seed=7, beta_dis=1.0, beta_clf=1.0,
+                                            beta_gen=1.0, lambda_=10.0)))
+    np.savez_compressed(os.path.join(GOLD, 'stage2_small.npz'), **out)
+
+
 if __name__ == '__main__':
     print('[golden] inference vectors')
     gen_infer('f80', c_in=80, c_h1=16, c_h2=32, c_h3=16, E=8, c_h=32, n_spk=4,
@@ -267,4 +362,6 @@ if __name__ == '__main__':
     gen_classifier()
     print('[golden] vocoder')
     gen_vocoder()
+    print('[golden] stage 2 (PatchDiscriminator, WGAN-GP)')
+    gen_stage2()
     print('done ->', GOLD)

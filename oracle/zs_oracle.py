@@ -243,6 +243,118 @@ def cross_entropy(logits, y):
 
 
 # --------------------------------------------------------------------------
+# Stage 2: PatchDiscriminator / TargetClassifier (model/model.py:113-228), the WGAN-GP
+# gradient penalty (utils.py:58-77) and the patchGAN losses (trainer.py:257-263, 467-560)
+# --------------------------------------------------------------------------
+
+
+def pad_conv2d(x, w, b, seg_len, stride=1):
+    """pad_layer(..., is_2d=True), model/model.py:29-39: (k//2, k//2 | k//2 - 1) on both spatial axes, reflect when the
+    constructor seg_len >= 64."""
+    k = w.shape[2]
+    pl, pr = pad_amounts(k)
+    xp = F.pad(x, pad=(pl, pr, pl, pr), mode='constant' if seg_len < 64 else 'reflect')
+    return F.conv2d(xp, w, b, stride=stride)
+
+
+def instance_norm2d(x, eps=1e-5):
+    """nn.InstanceNorm2d defaults (no affine, biased variance) over (H, W) per (b, c)."""
+    mean = x.mean(dim=(2, 3), keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=(2, 3), keepdim=True)
+    return (x - mean) / torch.sqrt(var + eps)
+
+
+def dropout2d(x, p, training, mask=None):
+    """nn.Dropout2d: whole (b, c) feature maps are zeroed.  `mask` [B, C] (0/1 keep) makes it deterministic."""
+    if not training or p == 0.0:
+        return x
+    if mask is not None:
+        return x * mask[:, :, None, None] / (1.0 - p)
+    return F.dropout2d(x, p=p, training=True)
+
+
+def patch_discriminator_forward(sd, x, ns, seg_len, classify=False, dp=0.1, training=True, drop_masks=None, prefix=''):
+    """PatchDiscriminator.forward (model/model.py:155-173) / TargetClassifier.forward (:218-228, classify only).
+    x [B, 513, T] -> mean_val [B] (, logits [B, n_class]).  `prefix` 'module.' for DataParallel-wrapped state dicts."""
+    dm = drop_masks if drop_masks is not None else [None] * 6
+    out = x.unsqueeze(1)
+    for i in range(1, 7):
+        w, b = sd['%sconv%d.weight' % (prefix, i)], sd['%sconv%d.bias' % (prefix, i)]
+        out = F.leaky_relu(pad_conv2d(out, w, b, seg_len, stride=2 if i <= 5 else 1), negative_slope=ns)     # conv_block :148-153
+        out = dropout2d(instance_norm2d(out), dp, training, dm[i - 1])
+    mean_val = None
+    if (prefix + 'conv7.weight') in sd:
+        val = F.conv2d(out, sd[prefix + 'conv7.weight'], sd[prefix + 'conv7.bias'])
+        mean_val = val.view(val.size(0), -1).mean(dim=1)
+    if classify:
+        logits = F.conv2d(out, sd[prefix + 'conv_classify.weight'], sd[prefix + 'conv_classify.bias'])
+        return mean_val, logits.view(logits.size(0), -1)
+    return mean_val
+
+
+def synthetic_patch_sd(n_class, seed, seg_len=128, prefix=''):
+    """Deterministic PatchDiscriminator parameters from numpy's frozen legacy generator (model/model.py:114-131 shapes):
+    the 10.9 M weights of a stage-2 golden vector are regenerated from (n_class, seed) instead of being stored."""
+    rng = np.random.RandomState(seed)
+    kt = {128: 4, 64: 2, 32: 1}[seg_len]
+    shapes = [('conv1', (64, 1, 5, 5)), ('conv2', (128, 64, 5, 5)), ('conv3', (256, 128, 5, 5)), ('conv4', (512, 256, 5, 5)),
+              ('conv5', (512, 512, 5, 5)), ('conv6', (32, 512, 1, 1)), ('conv7', (1, 32, 17, kt)), ('conv_classify', (n_class, 32, 17, kt))]
+    sd = {}
+    for name, shp in shapes:
+        fan_in = shp[1] * shp[2] * shp[3]
+        sd[prefix + name + '.weight'] = torch.from_numpy((rng.standard_normal(shp) / math.sqrt(fan_in)).astype(np.float32))
+        sd[prefix + name + '.bias'] = torch.from_numpy((rng.standard_normal(shp[0]) * 0.1).astype(np.float32))
+    return sd
+
+
+def gradients_penalty(sd, real, fake, alpha, ns, seg_len, dp=0.1, training=True, drop_masks=None, prefix=''):
+    """utils.calculate_gradients_penalty (utils.py:58-77) with the interpolation weights `alpha` [B] given (the reference draws
+    torch.rand(B)).  Differentiable w.r.t. the parameters in `sd` (create_graph)."""
+    a = alpha.view(-1, 1, 1)
+    inter = (a * real + (1 - a) * fake).detach().requires_grad_(True)
+    d = patch_discriminator_forward(sd, inter, ns, seg_len, dp=dp, training=training, drop_masks=drop_masks, prefix=prefix)
+    g = torch.autograd.grad(outputs=d, inputs=inter, grad_outputs=torch.ones_like(d), create_graph=True, retain_graph=True,
+                            only_inputs=True)[0]
+    gp = (1.0 - torch.sqrt(1e-12 + torch.sum(g.view(g.size(0), -1) ** 2, dim=1))) ** 2
+    return gp.mean()
+
+
+def patch_d_loss(sd, x_t, x_dec, c_shifted, alpha, hp, masks=None, prefix=''):
+    """The discriminator loss of trainer.py:488-494: -beta_dis * w_dis + beta_clf * CE(real_logits, c - shift) + lambda * gp.
+    masks: None or three lists of six [B, C] keep masks (real, fake, interpolate passes).  Returns (loss, w_dis, loss_clf, gp, real_logits)."""
+    m = masks if masks is not None else [None, None, None]
+    kw = dict(ns=hp['ns'], seg_len=hp['seg_len'], dp=hp.get('dp', 0.1), training=hp.get('training', True), prefix=prefix)
+    d_real, real_logits = patch_discriminator_forward(sd, x_t, classify=True, drop_masks=m[0], **kw)
+    d_fake, _ = patch_discriminator_forward(sd, x_dec, classify=True, drop_masks=m[1], **kw)
+    w_dis = torch.mean(d_real - d_fake)                                                  # trainer.py:261
+    gp = gradients_penalty(sd, x_t, x_dec, alpha, drop_masks=m[2], **kw)
+    loss_clf = cross_entropy(real_logits, c_shifted)
+    loss = -hp['beta_dis'] * w_dis + hp['beta_clf'] * loss_clf + hp['lambda_'] * gp
+    return loss, w_dis, loss_clf, gp, real_logits
+
+
+def gen_step(dec_sd, gen_sd, enc_act, c, shift_c, ns, seg_len, g_mode='targeted_residual'):
+    """Trainer.gen_step (trainer.py:266-278)."""
+    x_dec = decoder_forward(dec_sd, enc_act, c, ns, seg_len)
+    if g_mode == 'naive':
+        return x_dec + decoder_forward(gen_sd, enc_act, c, ns, seg_len)
+    if g_mode == 'targeted':
+        return x_dec + decoder_forward(gen_sd, enc_act, c - shift_c, ns, seg_len)
+    if g_mode == 'targeted_residual':
+        return x_dec + x_dec * decoder_forward(gen_sd, enc_act, c - shift_c, ns, seg_len, output_mask=True)
+    raise NotImplementedError(g_mode)
+
+
+def patch_g_loss(sd, x_gen, c_shifted, hp, masks=None, prefix=''):
+    """The generator loss of trainer.py:528-533: beta_clf * CE(fake_logits, c - shift) + beta_gen * (-mean D(x_gen))."""
+    kw = dict(ns=hp['ns'], seg_len=hp['seg_len'], dp=hp.get('dp', 0.1), training=hp.get('training', True), prefix=prefix)
+    d_fake, fake_logits = patch_discriminator_forward(sd, x_gen, classify=True, drop_masks=masks, **kw)
+    loss_adv = -torch.mean(d_fake)
+    loss_clf = cross_entropy(fake_logits, c_shifted)
+    return hp['beta_clf'] * loss_clf + hp['beta_gen'] * loss_adv, loss_adv, loss_clf, fake_logits
+
+
+# --------------------------------------------------------------------------
 # train_ae step  (trainer.py:320-332, utils.py:48-55, torch.optim.Adam)
 # --------------------------------------------------------------------------
 

@@ -172,3 +172,30 @@ def test_vocoder_pieces_pinned_to_scipy():
     assert np.abs(pre - scipy.signal.lfilter([1, -0.97], [1], y.astype(np.float64))).max() < 1e-6
     # ... and de_preemphasis inverts it
     assert np.abs(O.de_preemphasis(pre) - y).max() < 1e-4
+
+
+def test_stage2_golden():
+    """Stage 2 oracle (PatchDiscriminator forward, WGAN-GP double backward, patchGAN D / G losses) against the vectors
+    captured from the reference's own PatchDiscriminator + utils.calculate_gradients_penalty (oracle/make_golden.py)."""
+    d, m = load_golden('stage2_small.npz')
+    sd = O.synthetic_patch_sd(m['n_class'], m['seed'])
+    hp = dict(ns=m['ns'], seg_len=m['seg_len'], dp=m['dp'], training=True, beta_dis=m['beta_dis'], beta_clf=m['beta_clf'],
+              beta_gen=m['beta_gen'], lambda_=m['lambda_'])
+    masks = [[torch.from_numpy(d['mask.%d.%d' % (p, l)]).float() for l in range(6)] for p in range(4)]
+    x_t, x_dec, c, alpha = (torch.from_numpy(d[k]) for k in ('x_t', 'x_dec', 'c', 'alpha'))
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    loss, w_dis, l_clf, gp, logits = O.patch_d_loss(p, x_t, x_dec, c, alpha, hp, masks=masks[:3])
+    loss.backward()
+    assert abs(w_dis.item() - float(d['w_dis'])) < 1e-5 and abs(gp.item() - float(d['gp'])) < 1e-5 * max(1.0, float(d['gp']))
+    assert abs(loss.item() - float(d['loss_d'])) < 1e-5 * max(1.0, abs(float(d['loss_d'])))
+    assert np.abs(logits.detach().numpy() - d['real_logits']).max() < 1e-5
+    for k in p:
+        g = p[k].grad.reshape(-1)
+        ref = d['gD.sample.' + k]
+        got = g[::max(1, g.numel() // 512)][:512].numpy()
+        assert np.abs(got - ref).max() <= 1e-7 + 3e-4 * np.abs(ref).max(), k
+        assert abs(g.double().norm().item() - float(d['gD.norm.' + k])) <= 3e-4 * float(d['gD.norm.' + k]) + 1e-9, k
+    xo = x_dec.clone().requires_grad_(True)
+    lg, _, _, fl = O.patch_g_loss(sd, xo, c, hp, masks=masks[3])
+    dx, = torch.autograd.grad(lg, xo)
+    assert abs(lg.item() - float(d['loss_g'])) < 1e-5 and np.abs(dx.numpy() - d['dx_gen']).max() <= 3e-4 * np.abs(d['dx_gen']).max()

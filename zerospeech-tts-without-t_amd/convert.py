@@ -32,8 +32,8 @@ def _device():
     return torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
 
 
-def griffin_lim_batch(mags, n_iter=None, device=None, impl=None, tile_frames=0):
-    """mags: list of real [513, T_i] amplitude spectrograms.  Returns (wav [n, 200*(T_max-1)] on the device, lengths, lens).
+def griffin_lim_batch(mags, n_iter=None, device=None, impl=None, tile_frames=0, mag_padded=None):
+    """mags: list of real [513, T_i] amplitude spectrograms (or mag_padded).  Returns (wav [n, 200*(T_max-1)] on the device, lengths, lens).
     X = S (zero phase); n_iter x { x = istft(X); E = stft(x); X = S * E / max(1e-8, |E|) }; x = istft(X)  (convert.py:39-52).
     impl 'fused' (default): zs_griffin_lim -- one fused kernel per iteration, the whole loop issued by one C call;
     impl 'split' (ZS_GL_IMPL=split): the older per-transform kernels (zs_gl_istft + zs_gl_stft_project per iteration), kept as
@@ -42,18 +42,23 @@ def griffin_lim_batch(mags, n_iter=None, device=None, impl=None, tile_frames=0):
     impl = impl or os.environ.get('ZS_GL_IMPL', 'fused')
     dev = device or _device()
     st = torch.cuda.current_stream(dev).cuda_stream
-    n = len(mags)
-    lens = [int(m.shape[1]) for m in mags]
+    if mag_padded is not None:                    # (amplitudes [n, T_max, 513] fp32 on the device, frame counts)
+        mag, lens = mag_padded
+        n, Tm = mag.shape[0], mag.shape[1]
+    else:
+        n = len(mags)
+        lens = [int(m.shape[1]) for m in mags]
+        Tm = max(lens)
     if min(lens) < 4:
         raise ValueError('griffin_lim needs at least 4 frames (reflect padding of n_fft//2 = 512 samples on 200*(T-1) samples)')
-    Tm = max(lens)
-    mag = torch.zeros(n, Tm, 513, dtype=torch.float32, device=dev)
-    for i, m in enumerate(mags):
-        t = m if torch.is_tensor(m) else torch.as_tensor(np.asarray(m, dtype=np.float32))
-        mag[i, :lens[i]] = t.to(dev, torch.float32).t()
+    if mag_padded is None:
+        mag = torch.zeros(n, Tm, 513, dtype=torch.float32, device=dev)
+        for i, m in enumerate(mags):
+            t = m if torch.is_tensor(m) else torch.as_tensor(np.asarray(m, dtype=np.float32))
+            mag[i, :lens[i]] = t.to(dev, torch.float32).t()
     lengths = torch.tensor(lens, dtype=torch.int32, device=dev)
     spec = torch.zeros(n, Tm, 513, 2, dtype=torch.float32, device=dev)
-    spec[..., 0] = mag
+    spec[..., 0] = mag                            # X0 = S, zero phase; rows past an utterance's length are never read
     wav_ld = 200 * (Tm - 1)
     wav = torch.zeros(n, wav_ld, dtype=torch.float32, device=dev)
     if impl == 'fused':
@@ -82,14 +87,23 @@ def griffin_lim(spectrogram, n_iter=None, impl=None):
 
 
 def trim(wav, top_db=60, frame_length=2048, hop_length=512):
-    """librosa.effects.trim defaults restated (RMS of centred frames, dB relative to the max)."""
+    """librosa.effects.trim defaults restated (RMS of centred frames, dB relative to the max).  The frames overlap four
+    times (2048 / 512): the mean squares come from sums over 512-sample blocks, one pass over the signal."""
     y = np.asarray(wav, dtype=np.float64)
     if len(y) == 0:
         return y, (0, 0)
     yp = np.pad(y, frame_length // 2, mode='reflect')
     n_frames = 1 + (len(yp) - frame_length) // hop_length
-    idx = np.arange(frame_length)[None, :] + hop_length * np.arange(n_frames)[:, None]
-    mse = np.mean(yp[idx] ** 2, axis=1)
+    if frame_length % hop_length == 0:
+        r = frame_length // hop_length
+        nb = n_frames + r - 1
+        blocks = np.einsum('ij,ij->i', yp[:nb * hop_length].reshape(nb, hop_length), yp[:nb * hop_length].reshape(nb, hop_length))
+        cs = np.concatenate(([0.0], np.cumsum(blocks)))
+        mse = (cs[r:r + n_frames] - cs[:n_frames]) / frame_length
+        mse = np.maximum(mse, 0.0)
+    else:
+        idx = np.arange(frame_length)[None, :] + hop_length * np.arange(n_frames)[:, None]
+        mse = np.mean(yp[idx] ** 2, axis=1)
     db = 10.0 * np.log10(np.maximum(1e-10, mse)) - 10.0 * np.log10(np.maximum(1e-10, np.max(mse)))
     nz = np.flatnonzero(db > -top_db)
     if nz.size == 0:
@@ -99,16 +113,20 @@ def trim(wav, top_db=60, frame_length=2048, hop_length=512):
 
 
 def spectrogram2wav_batch(mags_tf, n_iter=None, do_trim=True):
-    """Batched spectrogram2wav (convert.py:55-62): list of [T_i, 513] normalised magnitudes -> list of float32 wavs."""
+    """Batched spectrogram2wav (convert.py:55-62): list of [T_i, 513] normalised magnitudes -> list of float32 wavs.
+    One padded host buffer, one H2D copy, one de-normalisation launch, one zs_griffin_lim call, one de-emphasis launch, one
+    D2H copy; only librosa.effects.trim (restated) runs per utterance on the host."""
     dev = _device()
     st = torch.cuda.current_stream(dev).cuda_stream
-    amps = []
-    for m in mags_tf:
-        t = torch.as_tensor(np.ascontiguousarray(np.asarray(m, dtype=np.float32))).to(dev)
-        a = torch.empty_like(t)
-        L.check(L.lib().zs_gl_denormalize(L.ptr(t), L.ptr(a), t.numel(), st), 'zs_gl_denormalize')
-        amps.append(a.t())                                    # [513, T]
-    wav, lengths, lens = griffin_lim_batch(amps, n_iter=n_iter, device=dev)
+    lens = [int(np.shape(m)[0]) for m in mags_tf]
+    n, Tm = len(lens), max(lens)
+    host = np.zeros((n, Tm, 513), dtype=np.float32)
+    for i, m in enumerate(mags_tf):
+        host[i, :lens[i]] = np.asarray(m, dtype=np.float32)
+    t = torch.from_numpy(host).to(dev)
+    amp = torch.empty_like(t)
+    L.check(L.lib().zs_gl_denormalize(L.ptr(t), L.ptr(amp), t.numel(), st), 'zs_gl_denormalize')     # convert.py:56-58
+    wav, lengths, lens = griffin_lim_batch(None, n_iter=n_iter, device=dev, mag_padded=(amp, lens))
     L.check(L.lib().zs_gl_deemphasis(L.ptr(wav), wav.shape[1], L.ptr(lengths), len(lens), float(hp.preemphasis), st),
             'zs_gl_deemphasis')                               # signal.lfilter([1], [1, -0.97], wav)
     w = wav.cpu().numpy()
