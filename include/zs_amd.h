@@ -397,6 +397,113 @@ int zs_pre_mel(const float* amp, const float* basis, float* mel, int64_t rows, i
 int zs_gl_denormalize(const float* mag_norm, float* mag_amp, int64_t n, void* stream);
 int zs_gl_deemphasis(float* wav, int64_t wav_ld, const int32_t* lengths, int32_t n_utt, float coef, void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * Stage 2 (model/model.py:113-228, trainer.py:257-294, 467-560, utils.py:58-77): PatchDiscriminator /
+ * TargetClassifier and the WGAN-GP penalty.
+ * Activations of the 2-D nets are channels-last [B, H, W, C] = B*H*W rows of ld elements with H = time and W = frequency, so
+ * the loader's [B, T, F] spectrogram IS the input [B, H=T, W=F, C=1] (the reference's Conv2d sees [B, 1, F, T]: its kernel
+ * index along F is the tap axis here, the one along T the gather axis).  A k x k / stride-s Conv2d (pad_layer is_2d) runs as
+ *   zs_conv2d_gather  : im2col along H only, Xh[(b,ho), w, kh*C + c] = X[b, pad(s*ho + kh - pad), w, c]   (k/s x the input)
+ *   zs_gemm_conv      : the existing implicit GEMM over W (taps along W, "batch" = (b, ho)) on the weight viewed as a Conv1d
+ *                       weight [Cout, k*C, k];  weight gradient = zs_gemm_wgrad on the same view
+ *   data gradient     : zs_gemm_conv(gather=1) into the W-padded domain, then zs_conv2d_fold (reflect folds along W, the
+ *                       transpose of the H gather) -- a gather-formulated sum in fixed order, no atomics. */
+typedef struct {
+  int32_t dtype;
+  const void* x; int64_t ldx; int32_t x_f32;     /* [B][H_in][Wd] rows of ldx elements, C valid; fp32 or T */
+  void* out; int64_t ldo;                         /* [B][H_out][Wd] rows of ldo >= k*C elements (T dtype; zeros past k*C) */
+  int32_t B, H_in, H_out, Wd, C;
+  int32_t k, stride, pad, pad_mode;
+} ZsConv2dGather;
+int zs_conv2d_gather(const ZsConv2dGather* p, void* stream);
+typedef struct {
+  int32_t dtype;
+  const void* gp; int64_t ldg;                    /* [B*H_out][Wd + 2*pad] rows, columns kh*C + c (zs_gemm_conv gather=1 output) */
+  void* out; int64_t ldo; int32_t out_f32;        /* [B][H_in][Wd] rows; T dtype: zero filled to fill_cols */
+  int32_t fill_cols;
+  const void* add; int64_t ldadd;                 /* optional rows added (T dtype, same shape as out) */
+  int32_t B, H_in, H_out, Wd, C;
+  int32_t k, stride, pad, pad_mode;
+} ZsConv2dFold;
+int zs_conv2d_fold(const ZsConv2dFold* p, void* stream);
+
+/* zs_row_moments: per (b, c) sums over the T rows of a sample, two-stage in a fixed order (no atomics):
+ *   u' = u - center_sum[b][c]*center_scale (if center_sum);  m = y ? lrelu'(y) : 1
+ *   s1 = sum u'*m;  s2 = sum u'*m*v' (v' = u' when v == u; skipped if s2 == NULL);  s3 = sum u*w (if w)
+ * Serves InstanceNorm2d forward (mean, then the centred second moment), its backward (sum g, sum g*a) and the three moments of
+ * its double backward. */
+typedef struct {
+  int32_t dtype;
+  const void* u; int64_t ldu;
+  const void* v; int64_t ldv;
+  const void* y; int64_t ldy; float slope;
+  const void* w; int64_t ldw;
+  const float* center_sum; float center_scale;
+  int32_t B, T, C;
+  float* s1; float* s2; float* s3;                /* [B][C] */
+  float* partial; size_t partial_bytes;           /* >= zs_row_moments_workspace(B, T, C) */
+} ZsRowMoments;
+size_t zs_row_moments_workspace(int32_t B, int32_t T, int32_t C);
+int zs_row_moments(const ZsRowMoments* p, void* stream);
+
+/* zs_in2d_*: nn.InstanceNorm2d (no affine, biased variance, eps) + nn.Dropout2d over [B, T = H*W, C] rows.
+ * dm[b][c] = keep / (1 - p) (1 when dropout is off); xhat = a * inv_dm (inv_dm = 1/dm, 0 for a dropped map).
+ *  finalize : mean = s1/n, rstd = 1/sqrt(q/n + eps)         (s1 = sum y, q = sum (y - mean)^2 from zs_row_moments)
+ *  fwd      : a = (y - mean) * rstd * dm
+ *  bwd      : gz = [rstd*dm*(ga - S1/n) - rstd*xhat*(S2 + S2x)/n] * lrelu'(y)          (S1 = sum ga, S2 = sum ga*a)
+ *  adj      : double backward of `bwd` for the gradient penalty: with gbar_y = gbar_z*lrelu'(y), A1 = sum gbar_y, A2 = sum gbar_y*a:
+ *               gbar_a = dm*rstd*(gbar_y - A1/n - xhat*inv_dm*A2/n)                       (adjoint of ga)
+ *               xbar_a = -inv_dm*rstd*(gbar_y*S2/n + ga*dm*inv_dm*A2/n)                   (adjoint of xhat, as a gradient w.r.t. a)
+ *             the adjoint of rstd, A3 = sum gbar_z*gz, is added to S2 (S2x) in the following `bwd` through the forward graph. */
+int zs_in2d_finalize(const float* s1, const float* q, float* mean, float* rstd, int64_t n_bc, int32_t T, float eps, void* stream);
+typedef struct {
+  int32_t dtype;
+  const void* y; int64_t ldy; void* a; int64_t lda;
+  const float* mean; const float* rstd; const float* dm;   /* dm may be NULL (1) */
+  int32_t B, T, C;
+} ZsIn2dFwd;
+int zs_in2d_fwd(const ZsIn2dFwd* p, void* stream);
+typedef struct {
+  int32_t dtype;
+  const void* ga; int64_t ldga; const void* ga2; int64_t ldga2;   /* ga2: optional second addend of the incoming gradient */
+  const void* a; int64_t lda; const void* y; int64_t ldy;
+  const float* S1; const float* S2; const float* S2x; const float* rstd; const float* dm;
+  float slope;
+  void* gz; int64_t ldgz;
+  int32_t B, T, C;
+} ZsIn2dBwd;
+int zs_in2d_bwd(const ZsIn2dBwd* p, void* stream);
+typedef struct {
+  int32_t dtype;
+  const void* gbz; int64_t ldgbz; const void* y; int64_t ldy; const void* a; int64_t lda; const void* ga; int64_t ldga;
+  const float* A1; const float* A2; const float* S2; const float* rstd; const float* dm;
+  float slope;
+  void* gba; int64_t ldgba; void* xba; int64_t ldxba;
+  int32_t B, T, C;
+} ZsIn2dAdj;
+int zs_in2d_adj(const ZsIn2dAdj* p, void* stream);
+
+/* utils.calculate_gradients_penalty (utils.py:58-77) around the double backward:
+ *  zs_lerp_rows : out[b] = alpha[b]*x[b] + (1 - alpha[b])*y[b]   (fp32 rows of n elements)
+ *  zs_gp_penalty: s_b = sqrt(1e-12 + sum g_b^2);  *gp = mean_b (1 - s_b)^2;  gbar[b] = scale * (2/B) * (s_b - 1)/s_b * g[b] */
+int zs_lerp_rows(const float* x, const float* y, const float* alpha, float* out, int32_t B, int64_t n, void* stream);
+int zs_gp_penalty(const float* g, int32_t B, int64_t n, float scale, float* s_out, float* gp_out, float* gbar, void* stream);
+
+/* Trainer.gen_step (trainer.py:266-278) and its gradient.  mode 0: x_gen = xd + m; 1 ('targeted_residual'): x_gen = xd + xd*m.
+ * bwd: dpre = dx_gen * (mode ? xd : 1) * (tanh_out ? 1 - m^2 : m*(1 - m))   -- gradient w.r.t. the generator's pre-activation.
+ * zs_l1_plain: loss = mean|a - b| (two-stage, fixed order), d = sign(a - b) * scale / n   (trainer.py:539 target-guided loss). */
+/* xd, m: fp32 [rows][ld_in] (the decoders' output rows), x_gen / dx_gen: fp32 [rows][F] contiguous (the discriminator's input) */
+int zs_gen_combine_fwd(const float* xd, const float* m, int64_t ld_in, float* x_gen, int64_t rows, int32_t F, int32_t mode, void* stream);
+typedef struct {
+  int32_t dtype;
+  const float* dx_gen; int64_t ld_dx; const float* xd; const float* m; int64_t ld_in;
+  void* dpre; int64_t ldo; int32_t fill_cols;                            /* T dtype rows */
+  int64_t rows; int32_t F; int32_t mode, tanh_out;
+} ZsGenCombineBwd;
+int zs_gen_combine_bwd(const ZsGenCombineBwd* p, void* stream);
+int zs_l1_plain(const float* a, const float* b, int64_t n, float scale, float* partial, float* loss_out, float* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,12 +2,13 @@
 
   python main.py --preprocess [--remake]                  (wav directories -> dataset container + index JSONs)
   python main.py --train_ae [--load_model] [--hps_path hps/zerospeech_english_1024.json] [--synthetic]
+  python main.py --train_p | --train_tgat [--load_model] [--synthetic]     (stage 2: patchGAN from an ae checkpoint)
   python main.py --test --enc_only | --test_encode        (needs the preprocessed HDF5 + a checkpoint)
   python main.py --test_single --s_speaker S015 --t_speaker V002 [--enc_only]      (one wav -> result.wav + result.txt)
 
 Multi-GPU training: `python -m torch.distributed.run --nproc-per-node N main.py --train_ae ...` (one
 process per GPU; gradients are averaged with RCCL).  Modes outside the stage-1 autoencoder path
-(--train_p, --train_tgat, --train_al, --train_c, --train_t, --cross_test,
+(--train_al, --train_c, --train_t, --cross_test,
 --test_classify, --encode, --test_asr) are not part of this build and exit with a clear error.
 """
 import argparse
@@ -17,13 +18,13 @@ import sys
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-OUT_OF_SCOPE = ['train_p', 'train_tgat', 'train_al', 'train_c', 'train_t', 'test_asr', 'cross_test', 'test_classify', 'encode']
+OUT_OF_SCOPE = ['train_al', 'train_c', 'train_t', 'test_asr', 'cross_test', 'test_classify', 'encode']
 
 
 def build_parser():
     p = argparse.ArgumentParser(description='zerospeech_project (MI355X autoencoder hot path)')
-    for flag in ['preprocess', 'train', 'train_ae', 'test', 'test_encode', 'test_single', 'load_model', 'enc_only', 'remake',
-                 'synthetic'] + OUT_OF_SCOPE:
+    for flag in ['preprocess', 'train', 'train_ae', 'train_p', 'train_tgat', 'test', 'test_encode', 'test_single', 'load_model', 'enc_only',
+                 'remake', 'synthetic'] + OUT_OF_SCOPE:
         p.add_argument('--' + flag, default=False, action='store_true')
     p.add_argument('--flag', type=str, default='train')
     p.add_argument('--g_mode', default='set_from_hps',
@@ -94,20 +95,32 @@ def main(argv=None):
                    args.index_target_path, args.speaker2id_path, seg_len=hps.seg_len, n_samples=hps.n_samples, dset=args.flag,
                    remake=args.remake)
 
-    if args.train or args.train_ae:
+    if args.train or args.train_ae or args.train_p or args.train_tgat:                   # main.py:129-162
         rank, world, _ = parallel.init_from_env()
+        n_syn = max(4 * hps.batch_size * world, 64)
         if args.synthetic:
-            dataset = SyntheticDataset(max(4 * hps.batch_size * world, 64), seg_len=hps.seg_len, n_speakers=hps.n_speakers)
+            dataset = SyntheticDataset(n_syn, seg_len=hps.seg_len, n_speakers=hps.n_speakers)
+            sourceset = SyntheticDataset(n_syn, seg_len=hps.seg_len, n_speakers=hps.n_speakers - hps.n_target_speakers, seed=1)
+            targetset = SyntheticDataset(n_syn, seg_len=hps.seg_len, n_speakers=hps.n_target_speakers, seed=2,
+                                         speaker_offset=hps.n_speakers - hps.n_target_speakers)
         else:
             dataset = Dataset(args.dataset_path, args.index_path, seg_len=hps.seg_len)
-        data_loader = DataLoader(dataset, hps.batch_size, rank=rank, world=world)      # disjoint per-rank shards of each global batch
+            sourceset = Dataset(args.dataset_path, args.index_source_path, seg_len=hps.seg_len)
+            targetset = Dataset(args.dataset_path, args.index_target_path, seg_len=hps.seg_len)
+        mk = lambda ds: DataLoader(ds, hps.batch_size, rank=rank, world=world)           # disjoint per-rank shards of each global batch
+        data_loader, source_loader, target_loader = mk(dataset), mk(sourceset), mk(targetset)
         os.makedirs(args.ckpt_dir, exist_ok=True)
         model_path = os.path.join(args.ckpt_dir, args.model_name)
         trainer = Trainer(hps, data_loader, args.g_mode, args.enc_mode, dtype=args.dtype)
         if args.load_model:
             trainer.load_model(os.path.join(args.ckpt_dir, args.load_train_model_name), load_model_list=hps.load_model_list)
-        trainer.train(model_path, args.flag, mode='pretrain_AE')
-        trainer.reset_keep()
+        if args.train or args.train_ae:
+            trainer.train(model_path, args.flag, mode='pretrain_AE')                     # stage 1: encoder-decoder reconstruction
+            trainer.reset_keep()
+        if args.train or args.train_p or args.train_tgat:
+            trainer.add_duo_loader(source_loader, target_loader)
+            trainer.train(model_path, args.flag, mode='patchGAN', target_guided=args.train_tgat)     # stage 2
+            trainer.reset_keep()
 
     if args.test or args.test_encode or args.test_single:
         os.makedirs(args.result_dir, exist_ok=True)

@@ -1,0 +1,187 @@
+"""Stage 2 on the GPU (BASELINE config 5): PatchDiscriminator forward, the patchGAN discriminator step with
+the WGAN-GP double backward, and the generator step, through the product code (zs_amd.patch / zs_amd.stage2) against the golden
+vectors captured from the reference's PatchDiscriminator + utils.calculate_gradients_penalty (tests/golden/stage2_small.npz; the
+10.9 M weights are regenerated from the seed by oracle.synthetic_patch_sd).
+
+Tolerances (fp32 path): values / logits 1e-3 of scale; parameter gradients of the D loss (including the second-order penalty
+term) 5e-3 of each tensor's scale on a strided sample of 512 entries + the tensor norm to 5e-3; dLoss_G/dx_gen 2e-3 of scale."""
+import io
+import json
+import os
+import sys
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import zs_amd  # noqa: F401
+    return torch.device('cuda:0')
+
+
+class _Hps(object):
+    def __init__(self, m):
+        self.beta_dis, self.beta_clf, self.beta_gen, self.lambda_ = m['beta_dis'], m['beta_clf'], m['beta_gen'], m['lambda_']
+        self.max_grad_norm, self.lr, self.n_speakers, self.n_target_speakers = 5.0, 1e-4, m['n_class'], m['n_class']
+
+
+def _setup(dev, dtype='fp32'):
+    import zs_oracle as O
+    from zs_amd.patch import PatchDiscriminator
+    d, m = load_golden('stage2_small.npz')
+    D = PatchDiscriminator(n_class=m['n_class'], ns=m['ns'], dp=m['dp'], seg_len=m['seg_len'], dtype=dtype).to(dev)
+    D.load_state_dict(O.synthetic_patch_sd(m['n_class'], m['seed']))
+    masks = [[torch.from_numpy(d['mask.%d.%d' % (p, l)]).float().to(dev) for l in range(6)] for p in range(4)]
+    return d, m, D, masks
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(1e-12, np.abs(b).max())
+
+
+def test_patch_discriminator_forward_golden(dev):
+    d, m, D, masks = _setup(dev)
+    D.train()
+    x_t = torch.from_numpy(d['x_t']).to(dev)                      # [B, 513, T], the reference's layout
+    val, logits = D(x_t, classify=True, drop_masks=masks[0])
+    assert _rel(val.cpu().numpy(), d['D_real']) < 1e-3 and _rel(logits.cpu().numpy(), d['real_logits']) < 1e-3
+    assert set(D.state_dict().keys()) == {'%s.%s' % (n, k) for n in ['conv%d' % i for i in range(1, 8)] + ['conv_classify'] for k in ('weight', 'bias')}
+
+
+def test_patchgan_d_step_with_gradient_penalty_golden(dev):
+    """w_dis, CE, gp and every PatchDiscriminator parameter gradient of -beta*w_dis + beta*CE + lambda*gp (trainer.py:488-494)."""
+    from zs_amd.stage2 import PatchGANStep
+    d, m, D, masks = _setup(dev)
+
+    class _Net(object):                                          # gen_step is bypassed: x_gen is given
+        def flat_params(self):
+            return D.flat_params()
+
+        def mark_dirty(self):
+            pass
+    step = PatchGANStep.__new__(PatchGANStep)
+    step.D, step.hps, step.g_mode, step.shift, step.device = D, _Hps(m), 'naive', 0, dev
+    step.loss_clf = torch.zeros(1, device=dev); step.correct = torch.zeros(1, dtype=torch.int32, device=dev)
+    x_t = torch.from_numpy(d['x_t']).permute(0, 2, 1).contiguous().to(dev)           # [B, T, F]
+    x_gen = torch.from_numpy(d['x_dec']).permute(0, 2, 1).contiguous().to(dev)
+    c = torch.from_numpy(d['c']).to(dev)
+    r = step.d_step(None, x_t, c, alpha=torch.from_numpy(d['alpha']).to(dev), masks=masks[:3], update=False, x_gen=x_gen)
+    torch.cuda.synchronize()
+    assert abs(r['w_dis'].item() - float(d['w_dis'])) < 1e-3 * max(1.0, abs(float(d['w_dis'])))
+    assert abs(r['real_loss_clf'].item() - float(d['loss_clf'])) < 1e-4
+    assert abs(r['gp'].item() - float(d['gp'])) < 2e-3 * max(1.0, float(d['gp'])), (r['gp'].item(), float(d['gp']))
+    worst = ('', 0.0)
+    for k, _ in D.named_parameters():
+        g = D.grad_view(k).detach().reshape(-1)
+        ref = d['gD.sample.' + k]
+        got = g[::max(1, g.numel() // 512)][:512].cpu().numpy()
+        e = np.abs(got - ref).max() / max(1e-9, np.abs(ref).max())
+        en = abs(g.double().norm().item() - float(d['gD.norm.' + k])) / max(1e-9, float(d['gD.norm.' + k]))
+        if max(e, en) > worst[1]:
+            worst = (k, max(e, en))
+        assert e < 5e-3 and en < 5e-3, (k, e, en)
+    print('worst D-gradient error (sample / norm, relative): %s %.3g; gp %.5f (reference %.5f)' % (worst + (r['gp'].item(), float(d['gp']))))
+
+
+def test_patchgan_g_step_input_gradient_golden(dev):
+    """The generator loss and its gradient w.r.t. the generated spectrogram (what flows into the Generator), trainer.py:524-533."""
+    from zs_amd.stage2 import PatchGANStep
+    d, m, D, masks = _setup(dev)
+    step = PatchGANStep.__new__(PatchGANStep)
+    step.D, step.hps, step.g_mode, step.shift, step.device = D, _Hps(m), 'naive', 0, dev
+    step.loss_clf = torch.zeros(1, device=dev); step.correct = torch.zeros(1, dtype=torch.int32, device=dev)
+    x_gen = torch.from_numpy(d['x_dec']).permute(0, 2, 1).contiguous().to(dev)
+    c = torch.from_numpy(d['c']).to(dev)
+    r = step.g_step(None, x_gen, c, masks=masks[3], update=False, x_gen=x_gen)
+    torch.cuda.synchronize()
+    assert abs(r['loss_adv'].item() - float(d['loss_adv'])) < 1e-3 * max(1.0, abs(float(d['loss_adv'])))
+    assert _rel(r['fake_logits'].cpu().numpy(), d['fake_logits']) < 1e-3
+    dx = r['dx_gen'].permute(0, 2, 1).cpu().numpy()                                  # -> [B, 513, T]
+    assert _rel(dx, d['dx_gen']) < 2e-3, _rel(dx, d['dx_gen'])
+
+
+def test_generator_chain_vs_oracle(dev):
+    """gen_step + the generator's parameter gradients through x_gen = x_dec + x_dec * G (targeted_residual) and a linear loss on
+    x_gen, against the oracle's autograd; and the target-guided L1 step."""
+    import zs_oracle as O
+    from zs_amd.model import Decoder, Encoder
+    from zs_amd.stage2 import PatchGANStep
+    torch.manual_seed(0)
+    E, ch, nspk, ntgt = 8, 32, 4, 2
+    enc = Encoder(c_in=513, c_h1=8, c_h2=32, c_h3=8, ns=0.01, dp=0.0, enc_size=E, seg_len=128, enc_mode='multilabel_binary', dtype='fp32').to(dev)
+    dec = Decoder(c_in=E, c_out=513, c_h=ch, c_a=nspk, ns=0.01, seg_len=128, dtype='fp32').to(dev)
+    gen = Decoder(c_in=E, c_out=513, c_h=ch, c_a=ntgt, ns=0.01, seg_len=128, output_mask=True, dtype='fp32').to(dev)
+
+    class H(object):
+        beta_dis = beta_clf = beta_gen = 1.0; lambda_ = 10.0; max_grad_norm = 5.0; lr = 1e-4; n_speakers = nspk; n_target_speakers = ntgt
+    step = PatchGANStep(enc, dec, gen, gen, H, 'targeted_residual')      # the discriminator slot is unused here
+    g = torch.Generator().manual_seed(3)
+    B, T = 2, 128
+    x = torch.rand(B, T, 513, generator=g)
+    c = torch.randint(nspk - ntgt, nspk, (B,), generator=g)
+    G = O.gumbel_from_uniform(torch.rand(B, T // 8, E, 2, generator=g))
+    wlin = torch.randn(B, T, 513, generator=g) * 1e-3
+    x_gen = step.gen_forward(x.to(dev), c.to(dev), True, noise=G.contiguous().to(dev), noise_kind=0)
+    step._gen_backward(wlin.to(dev).contiguous())
+    torch.cuda.synchronize()
+    esd = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    dsd = {k: v.detach().cpu() for k, v in dec.state_dict().items()}
+    gsd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in gen.state_dict().items()}
+    with torch.no_grad():
+        act, _ = O.encoder_forward(esd, x.permute(0, 2, 1), 0.01, 0.0, E, 128, G=G, training=True)
+    og = O.gen_step(dsd, gsd, act, c, nspk - ntgt, 0.01, 128, 'targeted_residual')         # [B, 513, T]
+    assert _rel(x_gen.permute(0, 2, 1).cpu().numpy(), og.detach().numpy()) < 1e-3
+    (og * wlin.permute(0, 2, 1)).sum().backward()
+    for k, _ in gen.named_parameters():
+        ref = gsd[k].grad if gsd[k].grad is not None else torch.zeros_like(gsd[k])
+        scale = ref.abs().max().item()
+        if scale < 1e-7:
+            continue
+        e = (gen.grad_view(k).cpu() - ref).abs().max().item() / scale
+        assert e < 3e-3, (k, e)
+    # target-guided step: L1(x_gen, x_t) and its update (no clipping)
+    before = gen.flat_params()[0].clone()
+    lrec = step.tg_step(x.to(dev), c.to(dev), noise=G.contiguous().to(dev), noise_kind=0)
+    torch.cuda.synchronize()
+    assert abs(lrec.item() - (og.detach() - x.permute(0, 2, 1)).abs().mean().item()) < 1e-5
+    assert not torch.equal(before, gen.flat_params()[0])
+    with pytest.raises(RuntimeError, match='target speakers'):
+        step.gen_forward(x.to(dev), torch.zeros(B, dtype=torch.int64, device=dev), False)
+
+
+def test_patchgan_loop_runs_and_checkpoints(dev, tmp_path, monkeypatch):
+    """Trainer.train(mode='patchGAN', target_guided=True) end to end on a narrow autoencoder (the discriminator has the reference's
+    fixed width): console lines, checkpoint dict with the two DataParallel-prefixed stage-2 entries, reload."""
+    from zs_amd.dataloader import DataLoader, SyntheticDataset
+    from zs_amd.hps import make_hps
+    from zs_amd.trainer import Trainer
+    monkeypatch.setenv('ZS_CKPT_EVERY', '2')
+    hps = make_hps(enc_size=8, emb_size=32, n_speakers=4, n_target_speakers=2, batch_size=2, patch_iters=2, n_patch_steps=2, max_to_keep=5)
+    src = DataLoader(SyntheticDataset(16, seg_len=128, n_speakers=2, seed=1), 2)
+    tgt = DataLoader(SyntheticDataset(16, seg_len=128, n_speakers=2, seed=2, speaker_offset=2), 2)
+    tr = Trainer(hps, None, hps.g_mode, hps.enc_mode, log_dir=str(tmp_path / 'log'), dtype='bf16', device=dev)
+    tr.add_duo_loader(src, tgt)
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        tr.train(str(tmp_path / 'm.pth'), 'train', mode='patchGAN', target_guided=True)
+    txt = buf.getvalue()
+    assert 'patch_D-1:[000002/000002], w_dis=' in txt and 'patch_G:[000002/000002], loss_adv=' in txt and 'tg_rec=' in txt
+    ck = torch.load(str(tmp_path / 'm.pth-s2-2'), map_location='cpu', weights_only=True)
+    assert set(ck.keys()) == {'encoder', 'decoder', 'generator', 'classifier', 'patch_discriminator', 'target_classifier'}
+    assert all(k.startswith('module.') for k in ck['patch_discriminator']) and 'module.conv_classify.weight' in ck['target_classifier']
+    assert all(torch.isfinite(v).all() for v in ck['patch_discriminator'].values())
+    tr2 = Trainer(hps, None, hps.g_mode, hps.enc_mode, log_dir=str(tmp_path / 'log'), dtype='bf16', device=dev)
+    with redirect_stdout(io.StringIO()):
+        tr2.load_model(str(tmp_path / 'm.pth-s2-2'), 'encoder, decoder, generator, patch_discriminator, target_classifier')
+    assert torch.equal(tr2.PatchDiscriminator.flat_params()[0], tr.PatchDiscriminator.flat_params()[0])

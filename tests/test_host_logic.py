@@ -155,7 +155,7 @@ def test_cli_surface(capsys):
     assert args.ckpt_dir == './ckpt_surprise' and args.dataset_path == './data/dataset_surprise.hdf5' and \
         args.synthesis_list == './data/surprise/synthesis.txt' and args.sub_result_dir == './surprise/'
     with pytest.raises(NotImplementedError):
-        main.main(['--train_p', '--hps_path', os.path.join(ROOT, 'hps', 'zerospeech_english.json')])
+        main.main(['--train_al', '--hps_path', os.path.join(ROOT, 'hps', 'zerospeech_english.json')])
 
 
 def _dp_worker(rank, world, port, q):

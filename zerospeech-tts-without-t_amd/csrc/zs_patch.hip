@@ -1,0 +1,554 @@
+// zs_patch.hip -- stage 2 (PatchDiscriminator / TargetClassifier, WGAN-GP): the pieces around the implicit-GEMM kernels that a
+// 2-D convolution stack needs (reference model/model.py:113-228, utils.py:58-77, trainer.py:257-294).
+//
+//  * Conv2d k x k / stride s on channels-last [B, H, W, C]: im2col along H only (zs_conv2d_gather, k/s times the input), then the
+//    existing zs_gemm_conv over W -- taps along W, reflect / zero padding and stride in its row gather, "batch" = (b, ho) --
+//    on the weight viewed as a Conv1d weight [Cout, k*C, k].  The data gradient comes back from zs_gemm_conv(gather=1) in the
+//    W-padded domain; zs_conv2d_fold applies the reflect folds along W and the transpose of the H gather as ONE gather-formulated
+//    sum per output element (fixed order, no atomics).
+//  * InstanceNorm2d + Dropout2d over T = H*W up to 16 448 rows per sample: statistics are two-stage column reductions
+//    (zs_row_moments: 512-row slabs -> partials -> fixed-order finish), the normalisation, its backward and the double backward
+//    of the gradient penalty are row-streaming elementwise kernels with per-(b, c) coefficients.  HBM-bound, 16-byte accesses.
+#include "zs_common.h"
+
+namespace {
+
+constexpr int NTP = 256;
+constexpr int MOM_ROWS = 512;      // rows of one partial slab of zs_row_moments
+
+__device__ __forceinline__ int pad_index(int s, int n, int mode, bool& valid) {
+  valid = true;
+  if (s >= 0 && s < n) return s;
+  if (mode == ZS_PAD_REFLECT) return zs_reflect(s, n);
+  valid = false;
+  return 0;
+}
+
+// ---- Conv2d: im2col along H ------------------------------------------------------------------------------------------------
+// one thread per (output row (b, ho, w), 8-element group of the k*C output columns): 16-byte stores; source elements of a
+// group may straddle two kh blocks when C is not a multiple of 8 (C = 1: the first layer), so the general path is per element.
+template <typename T>
+__global__ __launch_bounds__(NTP) void conv2d_gather_kernel(const ZsConv2dGather p) {
+  const int groups = (int)(p.ldo / 8);
+  const int64_t total = (int64_t)p.B * p.H_out * p.Wd * groups;
+  const int kc = p.k * p.C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % groups);
+    const int64_t row = i / groups;
+    const int w = (int)(row % p.Wd);
+    const int64_t bh = row / p.Wd;
+    const int ho = (int)(bh % p.H_out), b = (int)(bh / p.H_out);
+    float o[8];
+    const int col0 = g * 8;
+    if ((p.C & 7) == 0 && col0 < kc) {                       // the 8 columns lie inside one kh block: one 16-byte (32-byte) load
+      const int kh = col0 / p.C, c = col0 - kh * p.C;
+      bool valid;
+      const int hi = pad_index(p.stride * ho + kh - p.pad, p.H_in, p.pad_mode, valid);
+      if (valid) {
+        const int64_t src = (((int64_t)b * p.H_in + hi) * p.Wd + w) * p.ldx + c;
+        if (p.x_f32) load8<float>((const float*)p.x + src, o);
+        else load8<T>((const T*)p.x + src, o);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int col = col0 + e;
+        float v = 0.f;
+        if (col < kc) {
+          const int kh = col / p.C, c = col - kh * p.C;
+          bool valid;
+          const int hi = pad_index(p.stride * ho + kh - p.pad, p.H_in, p.pad_mode, valid);
+          if (valid) {
+            const int64_t src = (((int64_t)b * p.H_in + hi) * p.Wd + w) * p.ldx + c;
+            v = p.x_f32 ? ((const float*)p.x)[src] : Elem<T>::ld((const T*)p.x + src);
+          }
+        }
+        o[e] = v;
+      }
+    }
+    store8<T>((T*)p.out + row * p.ldo + col0, o);
+  }
+}
+
+// ---- Conv2d data gradient: fold the W-padded / H-gathered gradient back -----------------------------------------------------
+// dX[b, hi, w, c] = sum over (ph in {hi and its reflection partners}, kh with (ph + pad - kh) % stride == 0 -> ho) and over
+//                   (wp in {w + pad and its reflection partners}) of gp[(b, ho), wp, kh*C + c]
+template <typename T>
+__global__ __launch_bounds__(NTP) void conv2d_fold_kernel(const ZsConv2dFold p) {
+  const int cols = p.out_f32 ? p.C : p.fill_cols;
+  const int groups = (cols + 7) / 8;
+  const int64_t total = (int64_t)p.B * p.H_in * p.Wd * groups;
+  const int Wp = p.Wd + 2 * p.pad;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % groups);
+    const int64_t row = i / groups;
+    const int w = (int)(row % p.Wd);
+    const int64_t bh = row / p.Wd;
+    const int hi = (int)(bh % p.H_in), b = (int)(bh / p.H_in);
+    const int c0 = g * 8;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    // candidate positions in the (unpadded-coordinate) extended domains
+    int hs[3], ws[3], nh = 0, nw = 0;
+    hs[nh++] = hi;
+    ws[nw++] = w;
+    if (p.pad_mode == ZS_PAD_REFLECT) {
+      if (hi >= 1 && hi <= p.pad) hs[nh++] = -hi;
+      if (hi <= p.H_in - 2 && hi >= p.H_in - 1 - p.pad) hs[nh++] = 2 * (p.H_in - 1) - hi;
+      if (w >= 1 && w <= p.pad) ws[nw++] = -w;
+      if (w <= p.Wd - 2 && w >= p.Wd - 1 - p.pad) ws[nw++] = 2 * (p.Wd - 1) - w;
+    }
+    for (int a = 0; a < nh; ++a) {
+      for (int kh = 0; kh < p.k; ++kh) {
+        const int num = hs[a] + p.pad - kh;
+        if (num < 0 || num % p.stride != 0) continue;
+        const int ho = num / p.stride;
+        if (ho >= p.H_out) continue;
+        for (int q = 0; q < nw; ++q) {
+          const int wp = ws[q] + p.pad;                       // index in the padded W domain
+          const T* src = (const T*)p.gp + (((int64_t)b * p.H_out + ho) * Wp + wp) * p.ldg + (int64_t)kh * p.C + c0;
+          if ((p.C & 7) == 0) {
+            float v[8];
+            load8<T>(src, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (c0 + e < p.C) acc[e] += Elem<T>::ld(src + e);
+          }
+        }
+      }
+    }
+    if (p.add) {
+      const T* ad = (const T*)p.add + row * p.ldadd + c0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (c0 + e < p.C) acc[e] += Elem<T>::ld(ad + e);
+    }
+    if (p.out_f32) {
+      float* o = (float*)p.out + row * p.ldo + c0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (c0 + e < p.C) o[e] = acc[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (c0 + e >= p.C) acc[e] = 0.f;
+      store8<T>((T*)p.out + row * p.ldo + c0, acc);
+    }
+  }
+}
+
+// ---- per-(b, c) moments over T rows --------------------------------------------------------------------------------------------
+// grid (C/64 chunks, B, slabs of MOM_ROWS rows); thread (cg = tid & 7, rg = tid >> 3): 8 channels of rows rg, rg + 32, ...
+template <typename T>
+__global__ __launch_bounds__(NTP) void row_moments_kernel(const ZsRowMoments p, int nslab) {
+  __shared__ float red[3][32 * 64];
+  const int tid = threadIdx.x, cg = tid & 7, rg = tid >> 3;
+  const int b = blockIdx.y, slab = blockIdx.z, c0 = blockIdx.x * 64 + cg * 8;
+  const bool cvalid = c0 < p.C;
+  float s1[8], s2[8], s3[8], ctr[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; s3[e] = 0.f; ctr[e] = 0.f; }
+  if (cvalid && p.center_sum) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ctr[e] = (c0 + e < p.C) ? p.center_sum[(int64_t)b * p.C + c0 + e] * p.center_scale : 0.f;
+  }
+  const int t_lo = slab * MOM_ROWS, t_hi = min(p.T, t_lo + MOM_ROWS);
+  if (cvalid) {
+    for (int t = t_lo + rg; t < t_hi; t += 32) {
+      const int64_t row = (int64_t)b * p.T + t;
+      float u[8], ur[8];
+      load8<T>((const T*)p.u + row * p.ldu + c0, ur);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) u[e] = ur[e] - ctr[e];
+      if (p.y) {
+        float yv[8];
+        load8<T>((const T*)p.y + row * p.ldy + c0, yv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) u[e] *= dlrelu_f(yv[e], p.slope);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s1[e] += u[e];
+      if (p.s2) {
+        if (p.v == p.u) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s2[e] += u[e] * u[e];
+        } else {
+          float v[8];
+          load8<T>((const T*)p.v + row * p.ldv + c0, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s2[e] += u[e] * v[e];
+        }
+      }
+      if (p.w) {
+        float wv[8];
+        load8<T>((const T*)p.w + row * p.ldw + c0, wv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s3[e] += ur[e] * wv[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[0][rg * 64 + cg * 8 + e] = s1[e]; red[1][rg * 64 + cg * 8 + e] = s2[e]; red[2][rg * 64 + cg * 8 + e] = s3[e]; }
+  __syncthreads();
+  if (tid < 192) {
+    const int m = tid >> 6, c = tid & 63;
+    float s = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) s += red[m][r * 64 + c];
+    const int cc = blockIdx.x * 64 + c;
+    if (cc < p.C) p.partial[(((int64_t)b * nslab + slab) * 3 + m) * p.C + cc] = s;
+  }
+}
+
+__global__ void row_moments_finish_kernel(const ZsRowMoments p, int nslab) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)p.B * p.C) return;
+  const int b = (int)(i / p.C), c = (int)(i % p.C);
+  float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int s = 0; s < nslab; ++s) {
+    const float* q = p.partial + ((int64_t)b * nslab + s) * 3 * p.C + c;
+    a1 += q[0]; a2 += q[p.C]; a3 += q[2 * (int64_t)p.C];
+  }
+  if (p.s1) p.s1[i] = a1;
+  if (p.s2) p.s2[i] = a2;
+  if (p.s3) p.s3[i] = a3;
+}
+
+__global__ void in2d_finalize_kernel(const float* s1, const float* q, float* mean, float* rstd, int64_t n, float invT, float eps) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  mean[i] = s1[i] * invT;
+  rstd[i] = 1.0f / sqrtf(q[i] * invT + eps);
+}
+
+// ---- row-streaming elementwise kernels: thread per (row, 8 channels) ------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NTP) void in2d_fwd_kernel(const ZsIn2dFwd p) {
+  const int groups = (p.C + 7) / 8;
+  const int64_t total = (int64_t)p.B * p.T * groups;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % groups);
+    const int64_t row = i / groups;
+    const int b = (int)(row / p.T), c0 = g * 8;
+    float y[8], o[8];
+    load8<T>((const T*)p.y + row * p.ldy + c0, y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c0 + e;
+      if (c < p.C) {
+        const int64_t bc = (int64_t)b * p.C + c;
+        o[e] = (y[e] - p.mean[bc]) * p.rstd[bc] * (p.dm ? p.dm[bc] : 1.f);
+      } else o[e] = 0.f;
+    }
+    store8<T>((T*)p.a + row * p.lda + c0, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTP) void in2d_bwd_kernel(const ZsIn2dBwd p) {
+  const int groups = (p.C + 7) / 8;
+  const int64_t total = (int64_t)p.B * p.T * groups;
+  const float invT = 1.0f / (float)p.T;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % groups);
+    const int64_t row = i / groups;
+    const int b = (int)(row / p.T), c0 = g * 8;
+    float ga[8], a[8], y[8], o[8];
+    load8<T>((const T*)p.ga + row * p.ldga + c0, ga);
+    if (p.ga2) {
+      float g2[8];
+      load8<T>((const T*)p.ga2 + row * p.ldga2 + c0, g2);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ga[e] += g2[e];
+    }
+    load8<T>((const T*)p.a + row * p.lda + c0, a);
+    load8<T>((const T*)p.y + row * p.ldy + c0, y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c0 + e;
+      if (c < p.C) {
+        const int64_t bc = (int64_t)b * p.C + c;
+        const float dm = p.dm ? p.dm[bc] : 1.f, inv_dm = dm > 0.f ? 1.f / dm : 0.f, r = p.rstd[bc];
+        const float s2 = p.S2[bc] + (p.S2x ? p.S2x[bc] : 0.f);
+        const float gy = r * dm * (ga[e] - p.S1[bc] * invT) - r * a[e] * inv_dm * s2 * invT;
+        o[e] = gy * dlrelu_f(y[e], p.slope);
+      } else o[e] = 0.f;
+    }
+    store8<T>((T*)p.gz + row * p.ldgz + c0, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTP) void in2d_adj_kernel(const ZsIn2dAdj p) {
+  const int groups = (p.C + 7) / 8;
+  const int64_t total = (int64_t)p.B * p.T * groups;
+  const float invT = 1.0f / (float)p.T;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % groups);
+    const int64_t row = i / groups;
+    const int b = (int)(row / p.T), c0 = g * 8;
+    float gbz[8], y[8], a[8], ga[8], o1[8], o2[8];
+    load8<T>((const T*)p.gbz + row * p.ldgbz + c0, gbz);
+    load8<T>((const T*)p.y + row * p.ldy + c0, y);
+    load8<T>((const T*)p.a + row * p.lda + c0, a);
+    load8<T>((const T*)p.ga + row * p.ldga + c0, ga);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c0 + e;
+      if (c < p.C) {
+        const int64_t bc = (int64_t)b * p.C + c;
+        const float dm = p.dm ? p.dm[bc] : 1.f, inv_dm = dm > 0.f ? 1.f / dm : 0.f, r = p.rstd[bc];
+        const float gby = gbz[e] * dlrelu_f(y[e], p.slope);
+        const float xhat = a[e] * inv_dm;
+        const float m3 = inv_dm * p.A2[bc] * invT;                          // mean(gbar_y * xhat)
+        o1[e] = dm * r * (gby - p.A1[bc] * invT - xhat * m3);
+        o2[e] = -inv_dm * r * (gby * p.S2[bc] * invT + ga[e] * dm * m3);
+      } else { o1[e] = 0.f; o2[e] = 0.f; }
+    }
+    store8<T>((T*)p.gba + row * p.ldgba + c0, o1);
+    store8<T>((T*)p.xba + row * p.ldxba + c0, o2);
+  }
+}
+
+// ---- gradient penalty glue ----------------------------------------------------------------------------------------------------------
+__global__ void lerp_rows_kernel(const float* x, const float* y, const float* alpha, float* out, int B, int64_t n) {
+  const int64_t total = (int64_t)B * n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float a = alpha[i / n];
+    out[i] = a * x[i] + (1.f - a) * y[i];
+  }
+}
+
+// one 1024-thread workgroup per sample: s_b = sqrt(1e-12 + sum g^2) in double, fixed order
+__global__ __launch_bounds__(1024) void gp_norm_kernel(const float* g, int64_t n, float* s_out) {
+  __shared__ double red[16];
+  const float* gb = g + (int64_t)blockIdx.x * n;
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) { const double v = (double)gb[i]; acc += v * v; }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    s_out[blockIdx.x] = (float)sqrt(1e-12 + t);
+  }
+}
+
+__global__ void gp_finish_kernel(const float* g, const float* s, int B, int64_t n, float scale, float* gp_out, float* gbar) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && gp_out) {
+    float t = 0.f;
+    for (int b = 0; b < B; ++b) { const float d = 1.f - s[b]; t += d * d; }
+    *gp_out = t / (float)B;
+  }
+  if (!gbar) return;
+  const int64_t total = (int64_t)B * n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float sb = s[i / n];
+    gbar[i] = scale * (2.f / (float)B) * (sb - 1.f) / sb * g[i];
+  }
+}
+
+__global__ void gen_combine_fwd_kernel(const float* xd, const float* m, int64_t ld_in, float* xg, int64_t rows, int F, int mode) {
+  const int64_t n = rows * F;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = (i / F) * ld_in + (i % F);
+    xg[i] = mode ? xd[k] + xd[k] * m[k] : xd[k] + m[k];
+  }
+}
+
+template <typename T>
+__global__ void gen_combine_bwd_kernel(const ZsGenCombineBwd p) {
+  const int64_t total = p.rows * p.fill_cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / p.fill_cols;
+    const int c = (int)(i % p.fill_cols);
+    float v = 0.f;
+    if (c < p.F) {
+      const int64_t k = r * p.ld_in + c;
+      const float m = p.m[k];
+      v = p.dx_gen[r * p.ld_dx + c] * (p.mode ? p.xd[k] : 1.f) * (p.tanh_out ? (1.f - m * m) : m * (1.f - m));
+    }
+    Elem<T>::st((T*)p.dpre + r * p.ldo + c, v);
+  }
+}
+
+__global__ __launch_bounds__(NTP) void l1_plain_stage1(const float* a, const float* b, int64_t n, float scale, float* partial, float* d) {
+  __shared__ float red[NTP / 64];
+  float s = 0.f;
+  const float gs = scale / (float)n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float df = a[i] - b[i];
+    s += fabsf(df);
+    if (d) d[i] = df > 0.f ? gs : (df < 0.f ? -gs : 0.f);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void l1_plain_stage2(const float* partial, int nb, int64_t n, float* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < nb; ++i) t += (double)partial[i];
+    *out = (float)(t / (double)n);
+  }
+}
+
+unsigned grid_for(int64_t total) {
+  int64_t nb = (total + NTP - 1) / NTP;
+  if (nb > 16384) nb = 16384;
+  if (nb < 1) nb = 1;
+  return (unsigned)nb;
+}
+bool al16p(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+#define ZS_DT_OK(p) ZS_REQUIRE((p)->dtype == ZS_F32 || (p)->dtype == ZS_BF16, "bad dtype")
+
+extern "C" int zs_conv2d_gather(const ZsConv2dGather* p, void* stream) {
+  ZS_REQUIRE(p && p->x && p->out, "zs_conv2d_gather: null operand");
+  ZS_DT_OK(p);
+  const int es = p->dtype == ZS_F32 ? 4 : 2;
+  ZS_REQUIRE(p->B > 0 && p->H_in > 0 && p->H_out > 0 && p->Wd > 0 && p->C > 0 && p->k > 0 && p->stride > 0 && p->pad >= 0, "zs_conv2d_gather: sizes");
+  ZS_REQUIRE(p->ldo >= (int64_t)p->k * p->C && p->ldo % 8 == 0 && al16p(p->out), "zs_conv2d_gather: ldo %lld must be a multiple of 8 >= k*C", (long long)p->ldo);
+  ZS_REQUIRE(p->pad_mode != ZS_PAD_REFLECT || p->pad < p->H_in, "zs_conv2d_gather: Padding size should be less than the corresponding input dimension");
+  ZS_REQUIRE((p->stride * (p->H_out - 1) + p->k - 1 - p->pad) < p->H_in + p->pad, "zs_conv2d_gather: H_out too large");
+  if ((p->C & 7) == 0) ZS_REQUIRE(al16p(p->x) && (p->ldx * (p->x_f32 ? 4 : es)) % 16 == 0, "zs_conv2d_gather: alignment");
+  const int64_t total = (int64_t)p->B * p->H_out * p->Wd * (p->ldo / 8);
+  if (p->dtype == ZS_F32) hipLaunchKernelGGL(conv2d_gather_kernel<float>, dim3(grid_for(total)), dim3(NTP), 0, (hipStream_t)stream, *p);
+  else hipLaunchKernelGGL(conv2d_gather_kernel<bf16_t>, dim3(grid_for(total)), dim3(NTP), 0, (hipStream_t)stream, *p);
+  return zs_check_launch("zs_conv2d_gather");
+}
+
+extern "C" int zs_conv2d_fold(const ZsConv2dFold* p, void* stream) {
+  ZS_REQUIRE(p && p->gp && p->out, "zs_conv2d_fold: null operand");
+  ZS_DT_OK(p);
+  ZS_REQUIRE(p->B > 0 && p->H_in > 0 && p->H_out > 0 && p->Wd > 0 && p->C > 0 && p->k > 0 && p->stride > 0 && p->pad >= 0, "zs_conv2d_fold: sizes");
+  ZS_REQUIRE(p->ldg >= (int64_t)p->k * p->C && al16p(p->gp), "zs_conv2d_fold: ldg");
+  if (!p->out_f32) ZS_REQUIRE(p->fill_cols >= p->C && p->fill_cols % 8 == 0 && p->fill_cols <= p->ldo && al16p(p->out) && p->ldo % 8 == 0, "zs_conv2d_fold: fill_cols / ldo");
+  if ((p->C & 7) == 0) ZS_REQUIRE(p->ldg % 8 == 0, "zs_conv2d_fold: ldg alignment");
+  const int cols = p->out_f32 ? p->C : p->fill_cols;
+  const int64_t total = (int64_t)p->B * p->H_in * p->Wd * ((cols + 7) / 8);
+  if (p->dtype == ZS_F32) hipLaunchKernelGGL(conv2d_fold_kernel<float>, dim3(grid_for(total)), dim3(NTP), 0, (hipStream_t)stream, *p);
+  else hipLaunchKernelGGL(conv2d_fold_kernel<bf16_t>, dim3(grid_for(total)), dim3(NTP), 0, (hipStream_t)stream, *p);
+  return zs_check_launch("zs_conv2d_fold");
+}
+
+extern "C" size_t zs_row_moments_workspace(int32_t B, int32_t T, int32_t C) {
+  const size_t nslab = (size_t)((T + MOM_ROWS - 1) / MOM_ROWS);
+  return (size_t)B * nslab * 3 * (size_t)C * sizeof(float);
+}
+
+extern "C" int zs_row_moments(const ZsRowMoments* p, void* stream) {
+  ZS_REQUIRE(p && p->u && p->s1 && p->partial, "zs_row_moments: null operand");
+  ZS_DT_OK(p);
+  ZS_REQUIRE(p->B > 0 && p->T > 0 && p->C > 0 && p->C % 8 == 0, "zs_row_moments: sizes (C %% 8 == 0)");
+  ZS_REQUIRE(!p->s2 || p->v, "zs_row_moments: s2 needs v");
+  ZS_REQUIRE(!p->s3 || p->w, "zs_row_moments: s3 needs w");
+  ZS_REQUIRE(p->partial_bytes >= zs_row_moments_workspace(p->B, p->T, p->C), "zs_row_moments: workspace too small");
+  ZS_REQUIRE(al16p(p->u) && p->ldu % 8 == 0 && (!p->v || (al16p(p->v) && p->ldv % 8 == 0)) && (!p->y || (al16p(p->y) && p->ldy % 8 == 0)) &&
+                 (!p->w || (al16p(p->w) && p->ldw % 8 == 0)), "zs_row_moments: alignment");
+  const int nslab = (p->T + MOM_ROWS - 1) / MOM_ROWS;
+  ZS_REQUIRE(nslab <= 65535 && p->B <= 65535, "zs_row_moments: grid too large");
+  dim3 grid((unsigned)((p->C + 63) / 64), (unsigned)p->B, (unsigned)nslab);
+  if (p->dtype == ZS_F32) hipLaunchKernelGGL(row_moments_kernel<float>, grid, dim3(NTP), 0, (hipStream_t)stream, *p, nslab);
+  else hipLaunchKernelGGL(row_moments_kernel<bf16_t>, grid, dim3(NTP), 0, (hipStream_t)stream, *p, nslab);
+  int rc = zs_check_launch("zs_row_moments");
+  if (rc) return rc;
+  const int64_t n = (int64_t)p->B * p->C;
+  hipLaunchKernelGGL(row_moments_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p, nslab);
+  return zs_check_launch("zs_row_moments.finish");
+}
+
+extern "C" int zs_in2d_finalize(const float* s1, const float* q, float* mean, float* rstd, int64_t n_bc, int32_t T, float eps, void* stream) {
+  ZS_REQUIRE(s1 && q && mean && rstd && n_bc > 0 && T > 0, "zs_in2d_finalize: bad args");
+  hipLaunchKernelGGL(in2d_finalize_kernel, dim3((unsigned)((n_bc + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s1, q, mean, rstd, n_bc,
+                     1.0f / (float)T, eps);
+  return zs_check_launch("zs_in2d_finalize");
+}
+
+#define ZS_ROWS_OK(ptr, ld) (al16p(ptr) && (ld) % 8 == 0)
+
+extern "C" int zs_in2d_fwd(const ZsIn2dFwd* p, void* stream) {
+  ZS_REQUIRE(p && p->y && p->a && p->mean && p->rstd, "zs_in2d_fwd: null operand");
+  ZS_DT_OK(p);
+  ZS_REQUIRE(p->B > 0 && p->T > 0 && p->C > 0 && ZS_ROWS_OK(p->y, p->ldy) && ZS_ROWS_OK(p->a, p->lda) && p->lda >= ((p->C + 7) / 8) * 8, "zs_in2d_fwd: sizes / alignment");
+  const int64_t total = (int64_t)p->B * p->T * ((p->C + 7) / 8);
+  if (p->dtype == ZS_F32) hipLaunchKernelGGL(in2d_fwd_kernel<float>, dim3(grid_for(total)), dim3(NTP), 0, (hipStream_t)stream, *p);
+  else hipLaunchKernelGGL(in2d_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(NTP), 0, (hipStream_t)stream, *p);
+  return zs_check_launch("zs_in2d_fwd");
+}
+
+extern "C" int zs_in2d_bwd(const ZsIn2dBwd* p, void* stream) {
+  ZS_REQUIRE(p && p->ga && p->a && p->y && p->S1 && p->S2 && p->rstd && p->gz, "zs_in2d_bwd: null operand");
+  ZS_DT_OK(p);
+  ZS_REQUIRE(p->B > 0 && p->T > 0 && p->C > 0 && ZS_ROWS_OK(p->ga, p->ldga) && ZS_ROWS_OK(p->a, p->lda) && ZS_ROWS_OK(p->y, p->ldy) &&
+                 ZS_ROWS_OK(p->gz, p->ldgz) && (!p->ga2 || ZS_ROWS_OK(p->ga2, p->ldga2)), "zs_in2d_bwd: sizes / alignment");
+  const int64_t total = (int64_t)p->B * p->T * ((p->C + 7) / 8);
+  if (p->dtype == ZS_F32) hipLaunchKernelGGL(in2d_bwd_kernel<float>, dim3(grid_for(total)), dim3(NTP), 0, (hipStream_t)stream, *p);
+  else hipLaunchKernelGGL(in2d_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(NTP), 0, (hipStream_t)stream, *p);
+  return zs_check_launch("zs_in2d_bwd");
+}
+
+extern "C" int zs_in2d_adj(const ZsIn2dAdj* p, void* stream) {
+  ZS_REQUIRE(p && p->gbz && p->y && p->a && p->ga && p->A1 && p->A2 && p->S2 && p->rstd && p->gba && p->xba, "zs_in2d_adj: null operand");
+  ZS_DT_OK(p);
+  ZS_REQUIRE(p->B > 0 && p->T > 0 && p->C > 0 && ZS_ROWS_OK(p->gbz, p->ldgbz) && ZS_ROWS_OK(p->y, p->ldy) && ZS_ROWS_OK(p->a, p->lda) &&
+                 ZS_ROWS_OK(p->ga, p->ldga) && ZS_ROWS_OK(p->gba, p->ldgba) && ZS_ROWS_OK(p->xba, p->ldxba), "zs_in2d_adj: sizes / alignment");
+  const int64_t total = (int64_t)p->B * p->T * ((p->C + 7) / 8);
+  if (p->dtype == ZS_F32) hipLaunchKernelGGL(in2d_adj_kernel<float>, dim3(grid_for(total)), dim3(NTP), 0, (hipStream_t)stream, *p);
+  else hipLaunchKernelGGL(in2d_adj_kernel<bf16_t>, dim3(grid_for(total)), dim3(NTP), 0, (hipStream_t)stream, *p);
+  return zs_check_launch("zs_in2d_adj");
+}
+
+extern "C" int zs_lerp_rows(const float* x, const float* y, const float* alpha, float* out, int32_t B, int64_t n, void* stream) {
+  ZS_REQUIRE(x && y && alpha && out && B > 0 && n > 0, "zs_lerp_rows: bad args");
+  hipLaunchKernelGGL(lerp_rows_kernel, dim3(grid_for((int64_t)B * n)), dim3(NTP), 0, (hipStream_t)stream, x, y, alpha, out, (int)B, n);
+  return zs_check_launch("zs_lerp_rows");
+}
+
+extern "C" int zs_gp_penalty(const float* g, int32_t B, int64_t n, float scale, float* s_out, float* gp_out, float* gbar, void* stream) {
+  ZS_REQUIRE(g && s_out && B > 0 && n > 0, "zs_gp_penalty: bad args");
+  hipLaunchKernelGGL(gp_norm_kernel, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, g, n, s_out);
+  int rc = zs_check_launch("zs_gp_penalty.norm");
+  if (rc) return rc;
+  hipLaunchKernelGGL(gp_finish_kernel, dim3(grid_for(gbar ? (int64_t)B * n : 1)), dim3(NTP), 0, (hipStream_t)stream, g, (const float*)s_out, (int)B, n, scale,
+                     gp_out, gbar);
+  return zs_check_launch("zs_gp_penalty.finish");
+}
+
+extern "C" int zs_gen_combine_fwd(const float* xd, const float* m, int64_t ld_in, float* x_gen, int64_t rows, int32_t F, int32_t mode, void* stream) {
+  ZS_REQUIRE(xd && m && x_gen && rows > 0 && F > 0 && ld_in >= F, "zs_gen_combine_fwd: bad args");
+  hipLaunchKernelGGL(gen_combine_fwd_kernel, dim3(grid_for(rows * F)), dim3(NTP), 0, (hipStream_t)stream, xd, m, ld_in, x_gen, rows, (int)F, (int)mode);
+  return zs_check_launch("zs_gen_combine_fwd");
+}
+
+extern "C" int zs_gen_combine_bwd(const ZsGenCombineBwd* p, void* stream) {
+  ZS_REQUIRE(p && p->dx_gen && p->m && p->dpre && (!p->mode || p->xd), "zs_gen_combine_bwd: null operand");
+  ZS_DT_OK(p);
+  ZS_REQUIRE(p->rows > 0 && p->F > 0 && p->fill_cols >= p->F && p->fill_cols <= p->ldo && p->ld_in >= p->F && p->ld_dx >= p->F, "zs_gen_combine_bwd: sizes");
+  const int64_t total = p->rows * p->fill_cols;
+  if (p->dtype == ZS_F32) hipLaunchKernelGGL(gen_combine_bwd_kernel<float>, dim3(grid_for(total)), dim3(NTP), 0, (hipStream_t)stream, *p);
+  else hipLaunchKernelGGL(gen_combine_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(NTP), 0, (hipStream_t)stream, *p);
+  return zs_check_launch("zs_gen_combine_bwd");
+}
+
+extern "C" int zs_l1_plain(const float* a, const float* b, int64_t n, float scale, float* partial, float* loss_out, float* d, void* stream) {
+  ZS_REQUIRE(a && b && partial && loss_out && n > 0, "zs_l1_plain: bad args");
+  int64_t nb = (n + 4095) / 4096;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(l1_plain_stage1, dim3((unsigned)nb), dim3(NTP), 0, (hipStream_t)stream, a, b, n, scale, partial, d);
+  int rc = zs_check_launch("zs_l1_plain.stage1");
+  if (rc) return rc;
+  hipLaunchKernelGGL(l1_plain_stage2, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)partial, (int)nb, n, loss_out);
+  return zs_check_launch("zs_l1_plain.stage2");
+}

@@ -168,9 +168,9 @@ class SyntheticDataset(object):
     """n segments of U[1e-8,1) 'lin' spectrogram frames (the value range preprocess.py:247-252 produces)
     with random speaker ids; same item contract as Dataset.__getitem__."""
 
-    def __init__(self, n_items, seg_len=128, n_bins=513, n_speakers=102, seed=0, rank=0):
+    def __init__(self, n_items, seg_len=128, n_bins=513, n_speakers=102, seed=0, rank=0, speaker_offset=0):
         rng = np.random.RandomState(seed * 1000003 + rank)
-        self.spk = rng.randint(0, n_speakers, size=n_items).astype(np.int64)
+        self.spk = (rng.randint(0, n_speakers, size=n_items) + speaker_offset).astype(np.int64)
         self.lin = np.clip(rng.rand(n_items, seg_len, n_bins).astype(np.float32), 1e-8, 1.0)
 
     def __getitem__(self, i):

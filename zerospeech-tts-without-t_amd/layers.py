@@ -229,14 +229,14 @@ class ConvLayer(object):
         return (T_in + self.pad_l + self.pad_r - self.k) // self.stride + 1
 
     def fwd(self, A, out=None, act=L.ZS_ACT_NONE, slope=0.0, out_f32=False, out_cols=None, store_mode=L.ZS_STORE_ROWS,
-            out2=None, vec2=None, idx=None, store_mode2=L.ZS_STORE_ROWS, out2_cols=None, pre_vec=None):
+            out2=None, vec2=None, idx=None, store_mode2=L.ZS_STORE_ROWS, out2_cols=None, pre_vec=None, bias=True):
         """A: Act [B,T_in,Cin] -> out Act [B,T_out,Cout] (or pixel-shuffled).  Returns T_out."""
         c = self.ctx
         T_out = self.t_out(A.T)
         kw = dict(dtype=c.dt, A=A.ptr(), lda=A.ld, a_batch_stride=A.T * A.ld, B=A.B, T_in=A.T, T_out=T_out, taps=self.k,
                   stride=self.stride, pad_left=self.pad_l, pad_mode=self.pad_mode, gather=0, cin_pad=self.cin_pad,
-                  W=L.ptr(self.wf), ldw=self.ldw, N=self.Cout, n_pad=self.n_pad, bias=self.bias_ptr(), act=act, slope=slope,
-                  groups=1)
+                  W=L.ptr(self.wf), ldw=self.ldw, N=self.Cout, n_pad=self.n_pad, bias=(self.bias_ptr() if bias else None), act=act,
+                  slope=slope, groups=1)
         if pre_vec is not None:
             kw.update(pre_vec=L.ptr(pre_vec), pre_vec_ld=pre_vec.shape[1], vec_idx=L.ptr(idx))
         if out is not None:
@@ -266,8 +266,8 @@ class ConvLayer(object):
         L.call('zs_gemm_conv', 'ZsGemmConv', c.stream, **kw)
         return Tp
 
-    def wgrad(self, dY, X, accumulate=False):
-        """gw (+)= dY^T * gather(X);  gb (+)= column sums of dY (same kernel, no atomics)."""
+    def wgrad(self, dY, X, accumulate=False, bias=True):
+        """gw (+)= dY^T * gather(X);  gb (+)= column sums of dY (same kernel, no atomics; bias=False leaves gb alone)."""
         c = self.ctx
         es = c.es
         y_cols = min(dY.cols, rup(self.Cout, 16 // es))
@@ -275,7 +275,7 @@ class ConvLayer(object):
         kw = dict(dtype=c.dt, dY=dY.ptr(), ldy=dY.ld, y_cols=y_cols, X=X.ptr(), ldx=X.ld, x_batch_stride=X.T * X.ld,
                   x_cols=x_cols, B=X.B, T_in=X.T, T_out=dY.T, taps=self.k, stride=self.stride, pad_left=self.pad_l,
                   pad_mode=self.pad_mode, Cout=self.Cout, Cin=self.Cin, dW=L.ptr(self.gw), so=self.so, si=self.si, sj=self.sj,
-                  db=L.ptr(self.gb), co_split2=int(self.split2), accumulate=int(accumulate), splits=0)
+                  db=(L.ptr(self.gb) if bias else None), co_split2=int(self.split2), accumulate=int(accumulate), splits=0)
         wgrad_call(c, kw)
 
 

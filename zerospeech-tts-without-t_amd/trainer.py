@@ -20,6 +20,8 @@ from . import parallel
 from . import layers
 from .layers import Act, join_side
 from .model import Decoder, Encoder, SpeakerClassifier
+from .patch import PatchDiscriminator, TargetClassifier
+from .stage2 import PatchGANStep
 from .utils import Logger
 
 
@@ -388,13 +390,29 @@ class Trainer(object):
                                                                 (2 * enc_size if self.enc_mode == 'multilabel_binary' else enc_size)),
                                                    c_h=hps.emb_size, n_class=hps.n_speakers, dp=hps.dis_dp, seg_len=hps.seg_len,
                                                    dtype=dt).to(dev)
+        # ---stage two--- (trainer.py:85-97; nn.DataParallel there is a single-GPU identity: one process per GPU here)
+        self.PatchDiscriminator = PatchDiscriminator(ns=ns, n_class=(hps.n_speakers if self.g_mode == 'naive' else hps.n_target_speakers),
+                                                     seg_len=hps.seg_len, dtype=dt).to(dev)
+        self.TargetClassifier = TargetClassifier(ns=ns, n_class=3, seg_len=hps.seg_len, dtype=dt).to(dev)
         self.ae = AEStep(self.Encoder, self.Decoder, lr=hps.lr, betas=(0.5, 0.9), max_grad_norm=hps.max_grad_norm)
         self.clf = ClfStep(self.ae, self.SpeakerClassifier, lr=hps.lr, betas=(0.5, 0.9), max_grad_norm=hps.max_grad_norm)
+        self.s2 = None                      # PatchGANStep, built on first use (its optimizer state is 2 x 53 M floats)
+        self.source_loader = self.target_loader = None
         self.testing_shift_c = None
         self.sync_params()
 
     def nets(self):
-        return [self.Encoder, self.Decoder, self.Generator, self.SpeakerClassifier]
+        return [self.Encoder, self.Decoder, self.Generator, self.SpeakerClassifier, self.PatchDiscriminator, self.TargetClassifier]
+
+    def add_duo_loader(self, source_loader, target_loader):
+        """trainer.py:171-173."""
+        self.source_loader, self.target_loader = source_loader, target_loader
+        self._duo = None
+
+    def stage2(self):
+        if self.s2 is None:
+            self.s2 = PatchGANStep(self.Encoder, self.Decoder, self.Generator, self.PatchDiscriminator, self.hps, self.g_mode)
+        return self.s2
 
     def sync_params(self):
         """Data parallel: every rank starts from rank 0's weights (each process seeds torch's RNG differently, so the freshly
@@ -412,6 +430,11 @@ class Trainer(object):
             'generator': self.Generator.state_dict(),
             'classifier': self.SpeakerClassifier.state_dict(),
         }
+        if model_all:                                  # the reference wraps these two in nn.DataParallel: keys carry 'module.'
+            all_model['patch_discriminator'] = {'module.' + k: v for k, v in self.PatchDiscriminator.state_dict().items()}
+            all_model['target_classifier'] = {'module.' + k: v for k, v in self.TargetClassifier.state_dict().items()}
+        else:
+            del all_model['classifier']
         all_model = {k: {n: t.detach().cpu().clone() for n, t in sd.items()} for k, sd in all_model.items()}
         new_model_path = '{}-{}-{}'.format(model_path, name, iteration)
         torch.save(all_model, new_model_path)
@@ -427,11 +450,14 @@ class Trainer(object):
         all_model = torch.load(model_path, map_location='cpu', weights_only=True)
         if verbose:
             print('[Trainer] - ', end='')
+        strip = lambda sd: {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}
         for key, net, tag in (('encoder', self.Encoder, 'encoder'), ('decoder', self.Decoder, 'decoder'),
-                              ('generator', self.Generator, 'generator'), ('classifier', self.SpeakerClassifier, 'classifier')):
+                              ('generator', self.Generator, 'generator'), ('classifier', self.SpeakerClassifier, 'classifier'),
+                              ('patch_discriminator', self.PatchDiscriminator, 'patch_discriminator'),
+                              ('target_classifier', self.TargetClassifier, 'target_classifier')):
             if key in load_model_list:
                 try:
-                    net.load_state_dict(all_model[key])
+                    net.load_state_dict(strip(all_model[key]))
                     if verbose:
                         print('[%s], ' % tag, end='')
                 except Exception as e:                                   # reference: bare except, prints [x - X]
@@ -507,6 +533,15 @@ class Trainer(object):
             self._prefetch = DevicePrefetcher(self.data_loader, self.device)     # next batch copied under the current step
         return next(self._prefetch)
 
+    def _duo_batch(self):
+        """next(source_loader), next(target_loader) through the prefetcher (trainer.py:472-475)."""
+        if getattr(self, '_duo', None) is None:
+            from .dataloader import DevicePrefetcher
+            if self.source_loader is None or self.target_loader is None:
+                raise RuntimeError('patchGAN needs add_duo_loader(source_loader, target_loader)')
+            self._duo = (DevicePrefetcher(self.source_loader, self.device), DevicePrefetcher(self.target_loader, self.device))
+        return next(self._duo[0]), next(self._duo[1])
+
     def train(self, model_path, flag='train', mode='train', target_guided=False):
         hps = self.hps
         is_main = parallel.rank() == 0
@@ -580,5 +615,39 @@ class Trainer(object):
             layers.check_status(self.device)                                              # every rank, after the last step
             if is_main:
                 print()
+        elif mode == 'patchGAN':                                                          # trainer.py:467-560
+            s2 = self.stage2()
+            B = float(hps.batch_size)
+            for iteration in range(hps.patch_iters):
+                log_now = (iteration % self.log_every == 0) or (iteration + 1 == hps.patch_iters)
+                for step in range(hps.n_patch_steps):                                     # train D
+                    (_, x_s), (c_t, x_t) = self._duo_batch()
+                    r = s2.d_step(x_s, x_t, c_t)
+                    if log_now and is_main:
+                        info = {f'{flag}/w_dis': r['w_dis'].item(), f'{flag}/gp': r['gp'].item(), f'{flag}/real_loss_clf': r['real_loss_clf'].item(),
+                                f'{flag}/real_acc': r['correct'].item() / B}
+                        print('patch_D-%d:[%06d/%06d], w_dis=%.2f, gp=%.2f, loss_clf=%.2f, acc=%.2f' %
+                              ((step, iteration + 1, hps.patch_iters) + tuple(info.values())), end='\r')
+                        if iteration % 100 == 0:
+                            for tag, value in info.items():
+                                self.logger.scalar_summary(tag, value, iteration + 1)
+                (_, x_s), (c_t, x_t) = self._duo_batch()                                  # train G
+                r = s2.g_step(x_s, x_t, c_t)
+                loss_rec = s2.tg_step(x_t, c_t) if target_guided else None                # teacher forcing (trainer.py:535-541)
+                if log_now:
+                    layers.check_status(self.device)
+                if log_now and is_main:
+                    info = {f'{flag}/loss_adv': r['loss_adv'].item(), f'{flag}/fake_loss_clf': r['fake_loss_clf'].item(),
+                            f'{flag}/fake_acc': r['correct'].item() / B, f'{flag}/tg_rec': loss_rec.item() if target_guided else 0.000}
+                    print('patch_G:[%06d/%06d], loss_adv=%.2f, loss_clf=%.2f, acc=%.2f, tg_rec=%.3f' %
+                          ((iteration + 1, hps.patch_iters) + tuple(info.values())), end='\r')
+                    if iteration % 100 == 0:
+                        for tag, value in info.items():
+                            self.logger.scalar_summary(tag, value, iteration + 1)
+                if (iteration + 1) % self.ckpt_every == 0 and is_main:
+                    self.save_model(model_path, 's2', iteration + 1)
+            layers.check_status(self.device)
+            if is_main:
+                print()
         else:
-            raise NotImplementedError("mode %r (stage 2 / Tacotron) is outside the MI355X hot path this build covers" % mode)
+            raise NotImplementedError("mode %r (autolocker / t_classify / Tacotron) is outside the path this build covers" % mode)
