@@ -108,7 +108,15 @@ def test_patchgan_g_step_input_gradient_golden(dev):
     assert abs(r['loss_adv'].item() - float(d['loss_adv'])) < 1e-3 * max(1.0, abs(float(d['loss_adv'])))
     assert _rel(r['fake_logits'].cpu().numpy(), d['fake_logits']) < 1e-3
     dx = r['dx_gen'].permute(0, 2, 1).cpu().numpy()                                  # -> [B, 513, T]
-    assert _rel(dx, d['dx_gen']) < 2e-3, _rel(dx, d['dx_gen'])
+    # One of the 135 168 layer-4 pre-activations of this vector is zero to within fp32 rounding (|z| < 4e-6): the GPU's
+    # summation order puts it on the other side of the LeakyReLU kink (slope 0.01), its gradient differs by the factor 100 and the
+    # transposed convolutions above spread that over a 24 x 128 patch of one sample.  Hence: relative L2 error over everything,
+    # and the entries that are off by more than 2e-3 of the scale must be a small patch (< 0.5 %).
+    ref = d['dx_gen']
+    l2 = np.linalg.norm(dx - ref) / np.linalg.norm(ref)
+    off = (np.abs(dx - ref) > 2e-3 * np.abs(ref).max()).mean()
+    print('dLoss_G/dx_gen: relative L2 error %.3g, entries off by > 2e-3 of scale: %.3g %%' % (l2, 100 * off))
+    assert l2 < 5e-3 and off < 5e-3, (l2, off)
 
 
 def test_generator_chain_vs_oracle(dev):
@@ -185,3 +193,19 @@ def test_patchgan_loop_runs_and_checkpoints(dev, tmp_path, monkeypatch):
     with redirect_stdout(io.StringIO()):
         tr2.load_model(str(tmp_path / 'm.pth-s2-2'), 'encoder, decoder, generator, patch_discriminator, target_classifier')
     assert torch.equal(tr2.PatchDiscriminator.flat_params()[0], tr.PatchDiscriminator.flat_params()[0])
+
+
+def test_main_train_p_synthetic(dev, tmp_path, monkeypatch, capsys):
+    """`python main.py --train_p --synthetic` (main.py:155-158): source / target loaders, add_duo_loader, the patchGAN mode."""
+    sys.path.insert(0, ROOT)
+    import main
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv('ZS_CKPT_EVERY', '1')
+    dcfg = json.load(open(os.path.join(ROOT, 'hps', 'zerospeech_english.json')))
+    dcfg.update(enc_size=8, emb_size=32, n_speakers=4, n_target_speakers=2, batch_size=2, patch_iters=1, n_patch_steps=1)
+    hp_path = str(tmp_path / 'hps.json')
+    json.dump(dcfg, open(hp_path, 'w'))
+    main.main(['--train_p', '--synthetic', '--hps_path', hp_path, '--ckpt_dir', str(tmp_path / 'ck'), '--dtype', 'bf16'])
+    out = capsys.readouterr().out
+    assert 'patch_G:[000001/000001]' in out and 'pre_AE' not in out
+    assert os.path.exists(str(tmp_path / 'ck' / 'model.pth-s2-1'))
