@@ -357,11 +357,10 @@ def main():
     x = (torch.rand(B, seg_len, F, generator=g) * (1 - 1e-8) + 1e-8).to(dev)
     c = torch.randint(0, nspk, (B,), generator=g).to(dev)
 
-    prefetch = None
+    feeder = None
     if args.host_input:
-        # the batch comes from host memory every step through the DevicePrefetcher (pinned staging, copy stream, double buffer)
-        from zs_amd.dataloader import DevicePrefetcher
-
+        # every step's batch comes from HOST memory through trainer.HostFedStep: staged into pinned memory by the host, copied
+        # H2D by a node of the captured step (the copy of batch i+1 runs beside the kernels of step i)
         class _HostBatches(object):
             def __init__(self, c_host, x_host):
                 self.c, self.x = c_host, x_host
@@ -369,12 +368,11 @@ def main():
             def __next__(self):
                 return self.c, self.x
 
-        prefetch = DevicePrefetcher(_HostBatches(c.cpu().pin_memory(), x.cpu().pin_memory()), dev)
+        feeder = ae.host_feeder(_HostBatches(c.cpu(), x.cpu()))
 
     def one_step():
-        if prefetch is not None:
-            cb, xb = next(prefetch)                   # 67.2 MB H2D per step at B=256, issued one step ahead
-            return ae.step(xb, cb)
+        if feeder is not None:
+            return next(feeder)                       # 67.2 MB H2D per step at B=256
         return ae.step(x, c)
 
     ke = KernelEvents()
@@ -385,7 +383,7 @@ def main():
         for _ in range(3):
             one_step()
         torch.cuda.synchronize()
-        log('hipGraph captured (%d graph segment(s))' % sum(len(v['graphs']) for v in ae._graphs.values()))
+        log('hipGraph captured (%d graph segment(s))' % (sum(len(v['graphs']) for v in ae._graphs.values()) + (sum(len(e['graphs']) for e in feeder.ents) if feeder is not None and feeder.ents else 0)))
     for i in range(args.warmup):
         one_step()
         torch.cuda.synchronize()
@@ -412,7 +410,7 @@ def main():
         ae.use_graph = False
         ke.enabled = True
         for _ in range(min(10, max(3, args.steps))):
-            one_step()
+            ae.step(x, c)                              # (resident batch: only the kernel durations are read from these steps)
         torch.cuda.synchronize()
         ke.enabled = False
         ae.use_graph = True

@@ -463,3 +463,45 @@ def test_config3_two_ranks_on_one_gpu_gloo(dev, tmp_path):
     assert max(res['norm_rel_err']) < 1e-5, res
     assert max(res['param_err_over_lr']) < 0.05, res          # Adam moves every weight by ~lr: agreement to a few % of one move
     assert len(set(res['losses'])) == len(res['losses'])
+
+
+def test_host_fed_step_equals_resident_step(dev):
+    """trainer.HostFedStep (H2D copy of the next batch as a branch of the captured step): distinct host batches,
+    no host synchronisation between steps -- the loss trajectory and the parameters equal those of the same batches fed from
+    device memory through AEStep.step, bit for bit, and every batch is consumed exactly once in order."""
+    from zs_amd.model import Decoder, Encoder
+    from zs_amd.trainer import AEStep
+
+    class Loader(object):
+        def __init__(self):
+            self.g = torch.Generator().manual_seed(3)
+            self.n = 0
+
+        def __next__(self):
+            self.n += 1
+            return torch.randint(0, 4, (8,), generator=self.g), torch.rand(8, 128, 80, generator=self.g)
+
+    res = []
+    for mode in ('host', 'resident'):
+        torch.manual_seed(0)
+        enc = Encoder(c_in=80, c_h1=16, c_h2=64, c_h3=32, ns=0.01, dp=0.5, enc_size=32, seg_len=128, enc_mode='multilabel_binary', dtype='bf16').to(dev)
+        dec = Decoder(c_in=32, c_out=80, c_h=64, c_a=4, ns=0.01, seg_len=128, dtype='bf16').to(dev)
+        ae = AEStep(enc, dec, lr=1e-3, max_grad_norm=5.0, use_graph=True)
+        ld = Loader()
+        losses = []
+        if mode == 'host':
+            feeder = ae.host_feeder(ld)
+            for _ in range(9):
+                losses.append(next(feeder))
+            losses = [l.clone() for l in losses[-1:]] and losses
+            torch.cuda.synchronize()
+            final = ae._loss.item()
+        else:
+            for _ in range(9):
+                c, x = next(ld)
+                ae.step(x.to(dev), c.to(dev))
+            torch.cuda.synchronize()
+            final = ae._loss.item()
+        res.append((final, enc.flat_params()[0].clone(), dec.flat_params()[0].clone()))
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])

@@ -127,6 +127,17 @@ def check_status(device):
                         (' and '.join(n for b, n in ((1, 'forward'), (2, 'BPTT')) if v & b), v))
 
 
+_COPY = {}
+
+
+def copy_stream(device):
+    """The stream the in-graph H2D copy of the next batch runs on (trainer.HostFedStep)."""
+    key = (device.type, device.index)
+    if key not in _COPY:
+        _COPY[key] = torch.cuda.Stream(device)
+    return _COPY[key]
+
+
 class Ctx(object):
     """Per-model execution context: device, compute dtype, cached buffers, split-K workspace."""
 

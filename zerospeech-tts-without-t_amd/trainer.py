@@ -173,35 +173,40 @@ class AEStep(object):
             self._graphs[key] = ent
         ent['x'].copy_(x_btf, non_blocking=True)
         ent['c'].copy_(c, non_blocking=True)
-        if not multi:
-            ent['graphs'][0].replay()
-        else:
-            g1, g2, g3 = ent['graphs']
-            enc, dec = self.Encoder, self.Decoder
-            g1.replay()
-            self.reducer.start(dec.flat_params()[1])
-            g2.replay()
-            self.reducer.start(enc.flat_params()[1])
-            self.reducer.finish()
-            g3.replay()
-        self.adam_step += 1
+        self._replay(ent, multi)
         return self._loss
 
-    def _capture(self, x_btf, c, multi):
-        xs, cs = x_btf.clone(), c.clone()
+    def _capture(self, x_btf, c, multi, statics=None, prefetch=None):
+        """Capture the step on static inputs.  prefetch = (dst_x, src_x_pinned, dst_c, src_c_pinned): an H2D copy of the NEXT
+        batch captured as a parallel branch of the (first) graph -- it runs on its own stream beside the kernels of this step."""
+        xs, cs = statics if statics is not None else (x_btf.clone(), c.clone())
         torch.cuda.synchronize(self.device)
         st_ptr = L.ptr(self._seed_dev)
         graphs = []
         step0 = self.adam_step
 
         def seg1():
-            st = torch.cuda.current_stream(self.device).cuda_stream
+            main = torch.cuda.current_stream(self.device)
+            st = main.cuda_stream
+            ev_copy = None
+            if prefetch is not None:                               # fork: the copy engine works while the step computes
+                cs_ = layers.copy_stream(self.device)
+                ev0 = torch.cuda.Event()
+                ev0.record(main)
+                cs_.wait_event(ev0)
+                with torch.cuda.stream(cs_):
+                    prefetch[0].copy_(prefetch[1], non_blocking=True)
+                    prefetch[2].copy_(prefetch[3], non_blocking=True)
+                    ev_copy = torch.cuda.Event()
+                    ev_copy.record(cs_)
             L.check(L.lib().zs_step_counters(L.ptr(self._seed_dev), L.ptr(self._step_dev), st), 'zs_step_counters')
             self._seg_forward_decbwd(xs, cs, None, 2, None, parallel.rank(), st_ptr)
             if multi:
                 join_side(self.device)
             elif self.early_dec_update:
                 self._early_decoder_update()
+            if ev_copy is not None:
+                main.wait_event(ev_copy)                           # join inside the same graph
 
         def seg3():
             self._optimizer_device_step()
@@ -216,6 +221,24 @@ class AEStep(object):
             pool = g.pool()
             graphs.append(g)
         return {'graphs': graphs, 'x': xs, 'c': cs}
+
+    def _replay(self, ent, multi):
+        if not multi:
+            ent['graphs'][0].replay()
+        else:
+            g1, g2, g3 = ent['graphs']
+            g1.replay()
+            self.reducer.start(self.Decoder.flat_params()[1])
+            g2.replay()
+            self.reducer.start(self.Encoder.flat_params()[1])
+            self.reducer.finish()
+            g3.replay()
+        self.adam_step += 1
+
+    def host_feeder(self, loader):
+        """Iterator that runs one training step per `next()` on the batches of a HOST loader (`next(loader)` -> (c int64 [B],
+        x fp32 [B, T, F]) CPU tensors, the reference's DataLoader contract): see HostFedStep."""
+        return HostFedStep(self, loader)
 
     def grad_norms(self):
         """Squared per-net gradient norms as device scalars (Encoder, Decoder are clipped separately).  With more than one
@@ -245,6 +268,72 @@ class AEStep(object):
                    max_norm=self.max_grad_norm, write_clipped_grad=0, grad_scale=self.reducer.scale)
             net.mark_dirty()
         self._step_dev.fill_(self.adam_step)
+
+
+class HostFedStep(object):
+    """The --train_ae step fed from host memory with the H2D copy INSIDE the captured step (the reference
+    copies the 67 MB batch synchronously in front of every iteration, trainer.py:238-244).
+
+    Two static device inputs X[0], X[1] and two pinned staging buffers P[0], P[1]; graph k computes the step on X[k] and, as a
+    parallel branch on the copy stream, copies P[1-k] -> X[1-k] (the NEXT batch).  Step i replays graph i % 2, so the copy of batch
+    i+1 runs on the DMA engine beside the kernels of step i and costs no time on the critical path.  The host stages batch i+2 into
+    P[i % 2] after it has seen the end of step i-1 (the last reader of that buffer): it runs at most two steps ahead of the GPU.
+    Until the graphs exist (the AEStep's eager warm-up steps) batches go through a plain synchronous copy."""
+
+    def __init__(self, ae, loader):
+        self.ae, self.loader, self.dev = ae, loader, ae.device
+        self.i = 0
+        self.P = self.PC = self.X = self.C = None
+        self.ents = None
+        self.done = [torch.cuda.Event(), torch.cuda.Event()]
+        self._next = self._fetch()
+
+    def _fetch(self):
+        c, x = next(self.loader)[:2]
+        return c.long().contiguous(), x.float().contiguous()
+
+    def _alloc(self, c, x):
+        self.P = [torch.empty(x.shape, dtype=torch.float32).pin_memory() for _ in range(2)]
+        self.PC = [torch.empty(c.shape, dtype=torch.int64).pin_memory() for _ in range(2)]
+        self.X = [torch.empty(x.shape, dtype=torch.float32, device=self.dev) for _ in range(2)]
+        self.C = [torch.empty(c.shape, dtype=torch.int64, device=self.dev) for _ in range(2)]
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        ae = self.ae
+        multi = parallel.world_size() > 1
+        c, x = self._next
+        if self.P is None:
+            self._alloc(c, x)
+        if self.ents is None:
+            if ae._eager_calls < ae.graph_warmup or not ae.use_graph:       # warm-up (or graphs off): synchronous copy, eager launches
+                ae._eager_calls += 1
+                self.X[0].copy_(x); self.C[0].copy_(c)
+                if ae.use_graph:
+                    ae._counted_step_eager(self.X[0], self.C[0], multi)
+                else:
+                    ae.step(self.X[0], self.C[0])
+                self._next = self._fetch()
+                return ae._loss
+            # capture graph k on X[k] with the prefetch of the other slot as a branch; batch i -> X[0], batch i+1 -> P[1]
+            self.ents = [ae._capture(None, None, multi, statics=(self.X[k], self.C[k]),
+                                     prefetch=(self.X[1 - k], self.P[1 - k], self.C[1 - k], self.PC[1 - k])) for k in range(2)]
+            self.X[0].copy_(x); self.C[0].copy_(c)
+            self.i = 0
+            self._next = self._fetch()
+            self.P[1].copy_(self._next[1]); self.PC[1].copy_(self._next[0])
+        k = self.i % 2
+        ae._replay(self.ents[k], multi)                                       # step i on X[k]; P[1-k] -> X[1-k] beside it
+        self.done[k].record(torch.cuda.current_stream(self.dev))
+        # stage batch i+2 into P[k]: its last reader was graph 1-k at step i-1
+        self._next = self._fetch()                                            # = batch i+2 (batch i+1 is already in P[1-k])
+        if self.i >= 1:
+            self.done[1 - k].synchronize()
+        self.P[k].copy_(self._next[1]); self.PC[k].copy_(self._next[0])
+        self.i += 1
+        return ae._loss
 
 
 class ClfStep(object):
@@ -364,6 +453,7 @@ class Trainer(object):
             device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
         self.device = torch.device(device)
         self.log_every = int(os.environ.get('ZS_LOG_EVERY', '1'))
+        self.h2d_in_graph = os.environ.get('ZS_H2D_IN_GRAPH', '1') == '1'
         self.ckpt_every = int(os.environ.get('ZS_CKPT_EVERY', '1000'))     # the reference saves every 1000 iterations (trainer.py:345)
         self.build_model()
 
@@ -546,9 +636,13 @@ class Trainer(object):
         hps = self.hps
         is_main = parallel.rank() == 0
         if mode == 'pretrain_AE':                                                         # trainer.py:320-347
+            feeder = self.ae.host_feeder(self.data_loader) if (self.h2d_in_graph and self.ae.use_graph) else None
             for iteration in range(hps.enc_pretrain_iters):
-                c, x = self._batch()
-                loss_t = self.ae_step(x, c)
+                if feeder is not None:
+                    loss_t = next(feeder)                                                 # H2D of the next batch inside the captured step
+                else:
+                    c, x = self._batch()
+                    loss_t = self.ae_step(x, c)
                 if (iteration % self.log_every == 0) or (iteration + 1 == hps.enc_pretrain_iters):
                     loss_rec = loss_t.item()                                              # the only host sync
                     layers.check_status(self.device)                                      # ... so the GRU status word is read here
