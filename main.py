@@ -100,7 +100,7 @@ def main(argv=None):
         n_syn = max(4 * hps.batch_size * world, 64)
         if args.synthetic:
             dataset = SyntheticDataset(n_syn, seg_len=hps.seg_len, n_speakers=hps.n_speakers)
-            sourceset = SyntheticDataset(n_syn, seg_len=hps.seg_len, n_speakers=hps.n_speakers - hps.n_target_speakers, seed=1)
+            sourceset = SyntheticDataset(n_syn, seg_len=hps.seg_len, n_speakers=max(1, hps.n_speakers - hps.n_target_speakers), seed=1)
             targetset = SyntheticDataset(n_syn, seg_len=hps.seg_len, n_speakers=hps.n_target_speakers, seed=2,
                                          speaker_offset=hps.n_speakers - hps.n_target_speakers)
         else:

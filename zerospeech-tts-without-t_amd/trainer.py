@@ -290,11 +290,15 @@ class HostFedStep(object):
 
     def _fetch(self):
         c, x = next(self.loader)[:2]
-        return c.long().contiguous(), x.float().contiguous()
+        c = c.long().contiguous()
+        n_spk = self.ae.Decoder.c_a
+        if c.numel() and (int(c.min()) < 0 or int(c.max()) >= n_spk):         # an index outside the embedding tables would fault the GPU
+            raise ValueError('speaker index outside [0, %d) in the batch' % n_spk)
+        return c, x.float().contiguous()
 
     def _alloc(self, c, x):
-        self.P = [torch.empty(x.shape, dtype=torch.float32).pin_memory() for _ in range(2)]
-        self.PC = [torch.empty(c.shape, dtype=torch.int64).pin_memory() for _ in range(2)]
+        self.P = [torch.zeros(x.shape, dtype=torch.float32).pin_memory() for _ in range(2)]
+        self.PC = [torch.zeros(c.shape, dtype=torch.int64).pin_memory() for _ in range(2)]
         self.X = [torch.empty(x.shape, dtype=torch.float32, device=self.dev) for _ in range(2)]
         self.C = [torch.empty(c.shape, dtype=torch.int64, device=self.dev) for _ in range(2)]
 
@@ -318,8 +322,9 @@ class HostFedStep(object):
                 self._next = self._fetch()
                 return ae._loss
             # capture graph k on X[k] with the prefetch of the other slot as a branch; batch i -> X[0], batch i+1 -> P[1]
+            nopf = os.environ.get('ZS_DBG_NOPREFETCH') == '1'
             self.ents = [ae._capture(None, None, multi, statics=(self.X[k], self.C[k]),
-                                     prefetch=(self.X[1 - k], self.P[1 - k], self.C[1 - k], self.PC[1 - k])) for k in range(2)]
+                                     prefetch=(None if nopf else (self.X[1 - k], self.P[1 - k], self.C[1 - k], self.PC[1 - k]))) for k in range(2)]
             self.X[0].copy_(x); self.C[0].copy_(c)
             self.i = 0
             self._next = self._fetch()
@@ -331,7 +336,9 @@ class HostFedStep(object):
         self._next = self._fetch()                                            # = batch i+2 (batch i+1 is already in P[1-k])
         if self.i >= 1:
             self.done[1 - k].synchronize()
-        self.P[k].copy_(self._next[1]); self.PC[k].copy_(self._next[0])
+        self.PC[k].copy_(self._next[0])
+        if os.environ.get('ZS_DBG_NOSTAGE') != '1':                           # (probe: leaves stale spectrogram values, never stale indices)
+            self.P[k].copy_(self._next[1])
         self.i += 1
         return ae._loss
 
@@ -620,7 +627,7 @@ class Trainer(object):
     def _batch(self):
         if self._prefetch is None:
             from .dataloader import DevicePrefetcher
-            self._prefetch = DevicePrefetcher(self.data_loader, self.device)     # next batch copied under the current step
+            self._prefetch = DevicePrefetcher(self.data_loader, self.device, n_speakers=self.hps.n_speakers)   # next batch copied under the current step
         return next(self._prefetch)
 
     def _duo_batch(self):
@@ -629,7 +636,8 @@ class Trainer(object):
             from .dataloader import DevicePrefetcher
             if self.source_loader is None or self.target_loader is None:
                 raise RuntimeError('patchGAN needs add_duo_loader(source_loader, target_loader)')
-            self._duo = (DevicePrefetcher(self.source_loader, self.device), DevicePrefetcher(self.target_loader, self.device))
+            self._duo = (DevicePrefetcher(self.source_loader, self.device, n_speakers=self.hps.n_speakers),
+                         DevicePrefetcher(self.target_loader, self.device, n_speakers=self.hps.n_speakers))
         return next(self._duo[0]), next(self._duo[1])
 
     def train(self, model_path, flag='train', mode='train', target_guided=False):
