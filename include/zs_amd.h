@@ -331,6 +331,13 @@ typedef struct {
 } ZsAdam;
 int zs_adam_clip(const ZsAdam* p, void* stream);
 
+/* zs_host_fetch: dst[0..bytes) = src[0..bytes) by a KERNEL that reads pinned (device-accessible) host memory over PCIe with
+ * 16-byte loads, on a deliberately small grid (`workgroups`, 0 = 32; 8 loads in flight per lane cover the link's
+ * bandwidth-latency product).  It replaces the H2D memcpy of the next batch (trainer.py:238-244) inside the captured step: on
+ * this stack a memcpy node of a hipGraph is not overlapped with the graph's kernel nodes, a kernel node on a forked stream is.
+ * bytes must be a multiple of 16, both pointers 16-byte aligned. */
+int zs_host_fetch(const void* src, void* dst, size_t bytes, int32_t workgroups, void* stream);
+
 /* zs_step_counters: per-step device-side state for hipGraph replay (kernel arguments are frozen in a graph):
  * *seed += 0x9E3779B97F4A7C15, *step += 1.  Either pointer may be null. */
 int zs_step_counters(uint64_t* seed, int32_t* step, void* stream);

@@ -288,7 +288,14 @@ class DecoderEngine(object):
         H = ch // 2
         gi = c.act('d_gi' + tag, B, T, 6 * H)
         gates = c.raw('d_gates' + tag, B * T * 8 * H, c.tdt) if training else None
+        # capture-time hook (trainer.HostFedStep): a branch to run beside the GRU.  The hook marks the fork point and returns the
+        # launcher, which is called AFTER the main chain's next nodes are enqueued: the graph executor keeps the first-captured
+        # child of a node on the parent's queue, so the critical chain must be captured first (measured: otherwise the GRU waits
+        # for the whole fetch)
+        post = c.hooks['dec_gru_fwd']() if c.hooks.get('dec_gru_fwd') else None
         self.gru.fwd(xe, cat3, ch, gi, gates)                                                            # :352-356
+        if post is not None:
+            post()
         L.call('zs_add_rowvec', 'ZsAddRowvec', st, dtype=c.dt, x=None, vec=L.ptr(emb[4]), vec_ld=ch, idx=L.ptr(cidx),
                out=cat3.ptr(2 * ch), ldo=cat3.ld, B=B, T=T, C=ch, fill_cols=ch)                           # :357 append_emb
         h5 = c.act('d_h5' + tag, B, T, ch)
@@ -352,7 +359,8 @@ class DecoderEngine(object):
         dgh = c.act('d_dgh' + tag, B, T, 6 * H)
         gp = c.act('d_gpA' + tag, B, T + 2, ch)
         gpv = Act(gp.t, B, T, ch, gp.ld)
-        self.gru.bwd(dcat3, ch, cat3, ch, tp['gates'], tp['gru_in'], dgi, dgh, gpv)
+        post = c.hooks['dec_gru_bwd']() if c.hooks.get('dec_gru_bwd') else None
+        self.gru.bwd(dcat3, ch, cat3, ch, tp['gates'], tp['gru_in'], dgi, dgh, gpv, post_persist=post)
         dx = c.act('d_dxA' + tag, B, T, ch)
         self._combine(gpv, T, 0, 0, dx, emb_i=4, res_mode=L.ZS_RES_IDENTITY, res=dcat3.sub(0, ch))   # out+emb5 (:353)
         for j in (1, 0):

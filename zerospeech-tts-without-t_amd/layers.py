@@ -154,6 +154,7 @@ class Ctx(object):
         self.kc = 128 // self.es
         self._bufs = {}
         self._ws = None
+        self.hooks = {}              # capture-time hooks of the engines (name -> callable or None)
         # sticky status word of the persistent kernels (ZsGruFwd.status): OR-ed into on a bounded-spin timeout, never cleared by
         # the library; read at the host's own sync points by check_status()
         self.status = device_status(self.device)
@@ -410,8 +411,9 @@ class GruLayer(object):
         """Test hook: raise if the last persistent pass over this layer's work buffer timed out (synchronises)."""
         L.check(L.lib().zs_gru_check(L.ptr(self._work(B)), B, self.H, self.ctx.stream), 'zs_gru_check')
 
-    def bwd(self, dout, dout_col, out, out_col, gates, X, dgi, dgh, dX, add_src=None):
-        """BPTT + parameter gradients + input gradient dX (= dgi W_ih, + add_src)."""
+    def bwd(self, dout, dout_col, out, out_col, gates, X, dgi, dgh, dX, add_src=None, post_persist=None):
+        """BPTT + parameter gradients + input gradient dX (= dgi W_ih, + add_src).  post_persist: called right after the BPTT
+        launch (a capture-time hook: work that should run beside the persistent kernel)."""
         c, H = self.ctx, self.H
         B, T = X.B, X.T
         work = self._work(B)
@@ -419,6 +421,8 @@ class GruLayer(object):
                out=out.ptr(), ldo=out.ld, out_col=out_col, gates=L.ptr(gates), whh_t=L.ptr(self.whh_t), ldw=self.hh_ldw_t,
                n_pad=self.hh_npad_t, w_gstride=self.hh_npad_t * self.hh_ldw_t, dgi=dgi.ptr(), ldgi=dgi.ld, dgh=dgh.ptr(),
                ldgh=dgh.ld, work=L.ptr(work), work_bytes=work.numel() * 4, status=L.ptr(c.status))
+        if post_persist is not None:
+            post_persist()
         for d in range(2):
             # dW_hh[d] = sum_t dgh_t^T h_{t-1}  (dir 0: h_{t-1} = out[t-1]; dir 1: out[t+1]) ; zero rows outside
             wgrad_call(c, dict(dtype=c.dt, dY=dgh.ptr(3 * H * d), ldy=dgh.ld, y_cols=3 * H, X=out.ptr(out_col + d * H),

@@ -57,6 +57,8 @@ class AEStep(object):
         self.use_graph = (os.environ.get('ZS_GRAPH', '1') == '1') if use_graph is None else bool(use_graph)
         self.early_dec_update = os.environ.get('ZS_EARLY_DEC_UPDATE', '1') == '1'
         self._dec_updated = False
+        self.fetch_by_kernel = os.environ.get('ZS_FETCH_KERNEL', '1') == '1'     # in-graph H2D by zs_host_fetch instead of a memcpy node
+        self.fetch_wgs = int(os.environ.get('ZS_FETCH_WGS', '32'))
         self._graphs = {}            # (B, T, F) -> dict(graphs=[...], x=static x, c=static c)
         self._eager_calls = 0
         self.graph_warmup = 2        # eager steps (same launches) before the capture
@@ -68,6 +70,8 @@ class AEStep(object):
         ctx = ee.ctx
         B, T, F = x_btf.shape
         bits, _, _ = ee.forward(x_btf, True, noise=noise, noise_kind=noise_kind, seed=seed, drop_masks=drop_masks, seed_ptr=seed_ptr)
+        if getattr(self, '_after_encoder', None) is not None:
+            self._after_encoder()                                  # capture-time hook: fork the next batch's fetch here
         xdec = de.forward(bits, c, True)
         dlogit = de.ctx.act('t_dlogit_%d_%d' % (B, T), B, xdec.T, F)
         L.call('zs_l1_loss', 'ZsL1Loss', ctx.stream, dtype=ctx.dt, x_dec=xdec.ptr(), ld_dec=xdec.ld, x=L.ptr(x_btf), ldx=F,
@@ -185,35 +189,84 @@ class AEStep(object):
         graphs = []
         step0 = self.adam_step
 
+        state = {'ev': None}
+
+        def join_prefetch():
+            if state['ev'] is not None:                            # join inside the same graph
+                torch.cuda.current_stream(self.device).wait_event(state['ev'])
+                state['ev'] = None
+
         def seg1():
             main = torch.cuda.current_stream(self.device)
             st = main.cuda_stream
-            ev_copy = None
-            if prefetch is not None:                               # fork: the copy engine works while the step computes
+
+            def fork_prefetch(part=None, deferred=False):
+                """The fetch of the NEXT batch as a parallel branch of this graph.  part None: everything; 0 / 1: the index tensor +
+                the first / the second half of the spectrogram bytes.  deferred: mark the fork point now and return the launcher
+                (see DecoderEngine.forward: the critical chain's next nodes are captured before the branch)."""
                 cs_ = layers.copy_stream(self.device)
                 ev0 = torch.cuda.Event()
                 ev0.record(main)
+                if deferred:
+                    return lambda: launch_prefetch(part, cs_, ev0)
+                launch_prefetch(part, cs_, ev0)
+
+            def launch_prefetch(part, cs_, ev0):
                 cs_.wait_event(ev0)
                 with torch.cuda.stream(cs_):
-                    prefetch[0].copy_(prefetch[1], non_blocking=True)
-                    prefetch[2].copy_(prefetch[3], non_blocking=True)
-                    ev_copy = torch.cuda.Event()
-                    ev_copy.record(cs_)
+                    if self.fetch_by_kernel:                       # a kernel node that reads the pinned buffers over PCIe (zs_amd.h)
+                        nbx = prefetch[0].numel() * prefetch[0].element_size()
+                        half = (nbx // 2) // 16 * 16
+                        jobs = []
+                        if part in (None, 0):
+                            jobs.append((L.ptr(prefetch[3]), L.ptr(prefetch[2]), prefetch[2].numel() * prefetch[2].element_size()))
+                        lo, hi = (0, nbx) if part is None else ((0, half) if part == 0 else (half, nbx))
+                        jobs.append((L.ptr(prefetch[1]) + lo, L.ptr(prefetch[0]) + lo, hi - lo))
+                        for src, dst, nb in jobs:
+                            L.check(L.lib().zs_host_fetch(src, dst, nb, self.fetch_wgs, cs_.cuda_stream), 'zs_host_fetch')
+                    elif part in (None, 0):
+                        prefetch[0].copy_(prefetch[1], non_blocking=True)
+                        prefetch[2].copy_(prefetch[3], non_blocking=True)
+                    state['ev'] = torch.cuda.Event()
+                    state['ev'].record(cs_)
+
+            # Where the branch forks (ZS_FETCH_FORK = start | counters | encoder | gru): measured on this ROCm stack (DESIGN section 7)
+            # the graph executor does not run this branch truly beside the chain wherever it forks -- the 1.2 ms transfer costs
+            # 1.1-1.4 ms of step time; forking at the start and joining at the very end of the graph is the cheapest (12.99 vs
+            # 11.9 ms resident); `gru` puts the two halves beside the decoder's GRU forward / BPTT.
+            fork_at = os.environ.get('ZS_FETCH_FORK', 'start') if prefetch is not None else None
+            dctx = self.Decoder._engine().ctx
+            if fork_at == 'start':
+                fork_prefetch()
             L.check(L.lib().zs_step_counters(L.ptr(self._seed_dev), L.ptr(self._step_dev), st), 'zs_step_counters')
-            self._seg_forward_decbwd(xs, cs, None, 2, None, parallel.rank(), st_ptr)
+            if fork_at == 'counters':
+                fork_prefetch()
+            self._after_encoder = fork_prefetch if fork_at == 'encoder' else None
+            if fork_at == 'gru':
+                if os.environ.get('ZS_FETCH_SPLIT', '1') == '1':
+                    dctx.hooks['dec_gru_fwd'] = lambda: fork_prefetch(0, True)
+                    dctx.hooks['dec_gru_bwd'] = lambda: fork_prefetch(1, True)
+                else:
+                    dctx.hooks['dec_gru_fwd'] = lambda: fork_prefetch(None, True)
+            try:
+                self._seg_forward_decbwd(xs, cs, None, 2, None, parallel.rank(), st_ptr)
+            finally:
+                self._after_encoder = None
+                dctx.hooks.pop('dec_gru_fwd', None); dctx.hooks.pop('dec_gru_bwd', None)
             if multi:
                 join_side(self.device)
             elif self.early_dec_update:
                 self._early_decoder_update()
-            if ev_copy is not None:
-                main.wait_event(ev_copy)                           # join inside the same graph
-
+            if multi:
+                join_prefetch()                                    # three graphs: the branch must end inside the first
         def seg3():
             self._optimizer_device_step()
             self.adam_step = step0                             # capture does not execute: the caller counts the step
 
         pool = None
-        segs = [lambda: (seg1(), self._seg_encbwd(), seg3())] if not multi else [seg1, self._seg_encbwd, seg3]
+        # single rank: the fetch branch joins at the very END of the graph (wherever the executor schedules it, it then runs
+        # beside the encoder's backward instead of holding it up)
+        segs = [lambda: (seg1(), self._seg_encbwd(), seg3(), join_prefetch())] if not multi else [seg1, self._seg_encbwd, seg3]
         for seg in segs:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):   # other threads (RCCL watchdog) may call HIP
@@ -297,10 +350,18 @@ class HostFedStep(object):
         return c, x.float().contiguous()
 
     def _alloc(self, c, x):
-        self.P = [torch.zeros(x.shape, dtype=torch.float32).pin_memory() for _ in range(2)]
-        self.PC = [torch.zeros(c.shape, dtype=torch.int64).pin_memory() for _ in range(2)]
-        self.X = [torch.empty(x.shape, dtype=torch.float32, device=self.dev) for _ in range(2)]
-        self.C = [torch.empty(c.shape, dtype=torch.int64, device=self.dev) for _ in range(2)]
+        def pair(shape, dtype):
+            # storage rounded up to 16 bytes (zs_host_fetch granularity); zero-initialised: never a stale speaker index
+            n = 1
+            for d in shape:
+                n *= d
+            es = torch.empty(0, dtype=dtype).element_size()
+            n_pad = (n * es + 15) // 16 * 16 // es
+            host = [torch.zeros(n_pad, dtype=dtype).pin_memory() for _ in range(2)]
+            devt = [torch.zeros(n_pad, dtype=dtype, device=self.dev) for _ in range(2)]
+            return host, devt, [h[:n].view(shape) for h in host], [d[:n].view(shape) for d in devt]
+        self._Pfull, self._Xfull, self.P, self.X = pair(tuple(x.shape), torch.float32)
+        self._PCfull, self._Cfull, self.PC, self.C = pair(tuple(c.shape), torch.int64)
 
     def __iter__(self):
         return self
@@ -322,9 +383,9 @@ class HostFedStep(object):
                 self._next = self._fetch()
                 return ae._loss
             # capture graph k on X[k] with the prefetch of the other slot as a branch; batch i -> X[0], batch i+1 -> P[1]
-            nopf = os.environ.get('ZS_DBG_NOPREFETCH') == '1'
             self.ents = [ae._capture(None, None, multi, statics=(self.X[k], self.C[k]),
-                                     prefetch=(None if nopf else (self.X[1 - k], self.P[1 - k], self.C[1 - k], self.PC[1 - k]))) for k in range(2)]
+                                     prefetch=(self._Xfull[1 - k], self._Pfull[1 - k], self._Cfull[1 - k], self._PCfull[1 - k]))
+                         for k in range(2)]
             self.X[0].copy_(x); self.C[0].copy_(c)
             self.i = 0
             self._next = self._fetch()
@@ -337,8 +398,7 @@ class HostFedStep(object):
         if self.i >= 1:
             self.done[1 - k].synchronize()
         self.PC[k].copy_(self._next[0])
-        if os.environ.get('ZS_DBG_NOSTAGE') != '1':                           # (probe: leaves stale spectrogram values, never stale indices)
-            self.P[k].copy_(self._next[1])
+        self.P[k].copy_(self._next[1])
         self.i += 1
         return ae._loss
 
