@@ -505,3 +505,51 @@ def test_host_fed_step_equals_resident_step(dev):
         res.append((final, enc.flat_params()[0].clone(), dec.flat_params()[0].clone()))
     assert res[0][0] == res[1][0], (res[0][0], res[1][0])
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_micro_batch_lanes_equal_the_single_chain(dev, dtype):
+    """ZS_LANES = 2: the batch runs as two concurrent half-batch chains (own streams, buffers, tapes; the second lane accumulates
+    into the first one's parameter gradients).  With injected Gumbel noise and dropout masks the loss and every parameter
+    gradient equal the single-chain step up to the summation order of the weight gradients (fp32: 2e-5 of each tensor's scale;
+    bf16 operands are identical, so the same bound holds), and the hipGraph replay of the two-lane step is deterministic."""
+    import zs_oracle as O
+    from zs_amd.model import Decoder, Encoder
+    from zs_amd.trainer import AEStep
+    B, T, F_, E = 8, 128, 80, 32
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, T, F_, generator=g).to(dev)
+    c = torch.randint(0, 4, (B,), generator=g).to(dev)
+    G = O.gumbel_from_uniform(torch.rand(B, T // 8, E, 2, generator=g)).contiguous().to(dev)
+    masks = [(torch.rand(B, t, 64, generator=g) >= 0.5).to(torch.uint8).to(dev) for t in (T, T // 2, T // 4, T // 8, T // 8, T // 8)]
+    res = []
+    for lanes in (1, 2):
+        torch.manual_seed(0)
+        enc = Encoder(c_in=F_, c_h1=16, c_h2=64, c_h3=32, ns=0.01, dp=0.5, enc_size=E, seg_len=128, enc_mode='multilabel_binary', dtype=dtype).to(dev)
+        dec = Decoder(c_in=E, c_out=F_, c_h=64, c_a=4, ns=0.01, seg_len=128, dtype=dtype).to(dev)
+        ae = AEStep(enc, dec, lr=1e-3, max_grad_norm=5.0, use_graph=False)
+        ae.lanes = lanes
+        loss = ae.step(x, c, noise=G, noise_kind=0, drop_masks=masks, update=False).item()
+        torch.cuda.synchronize()
+        res.append((loss, enc.flat_params()[1].clone(), dec.flat_params()[1].clone(), {k: enc.grad_view(k).clone() for k, _ in enc.named_parameters()},
+                    {k: dec.grad_view(k).clone() for k, _ in dec.named_parameters()}))
+    assert abs(res[0][0] - res[1][0]) < 2e-6, (res[0][0], res[1][0])
+    for which in (3, 4):
+        for k, ref in res[0][which].items():
+            scale = ref.abs().max().item()
+            if scale < 1e-7:
+                continue
+            e = (res[1][which][k] - ref).abs().max().item() / scale
+            assert e < 2e-5, (k, e)
+    # graph replay of the two-lane step: two runs from the same state are bit-identical, the loss falls
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(0)
+        enc = Encoder(c_in=F_, c_h1=16, c_h2=64, c_h3=32, ns=0.01, dp=0.5, enc_size=E, seg_len=128, enc_mode='multilabel_binary', dtype=dtype).to(dev)
+        dec = Decoder(c_in=E, c_out=F_, c_h=64, c_a=4, ns=0.01, seg_len=128, dtype=dtype).to(dev)
+        ae = AEStep(enc, dec, lr=1e-3, max_grad_norm=5.0, use_graph=True)
+        ae.lanes = 2
+        losses = [ae.step(x, c).item() for _ in range(8)]
+        runs.append((losses, enc.flat_params()[0].clone(), dec.flat_params()[0].clone(), sum(len(v['graphs']) for v in ae._graphs.values())))
+    assert runs[0][3] == 1 and runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    assert runs[0][0][-1] < runs[0][0][0]

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Sweep the split-K plan knobs of the weight-gradient kernel and the number of side streams on the bench workload.
-# usage (on the GPU box): bash tools/sweep_wgrad.sh > gpurun_out/sweep_wgrad.log
-for cfg in "256 13 4" "128 13 4" "64 13 4" "256 26 4" "128 26 4" "128 26 6" "64 26 6" "256 13 8"; do
+# usage (on the GPU box): bash tools/sweep_wgrad.sh "256 13 4" "64 13 4" ...   (ZS_WGRAD_WGS ZS_WGRAD_SLAB_COST ZS_SIDE_STREAMS)
+for cfg in "$@"; do
   set -- $cfg
   echo "== ZS_WGRAD_WGS=$1 ZS_WGRAD_SLAB_COST=$2 ZS_SIDE_STREAMS=$3"
-  ZS_WGRAD_WGS=$1 ZS_WGRAD_SLAB_COST=$2 ZS_SIDE_STREAMS=$3 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-kernel-events 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ms_per_step %.3f  frames/s %.0f' % (d['ms_per_step'], d['value']))"
+  ZS_WGRAD_WGS=$1 ZS_WGRAD_SLAB_COST=$2 ZS_SIDE_STREAMS=$3 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-kernel-events 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ms_per_step %.3f  frames/s %.0f' % (d['ms_per_step'], d['value']))"
 done

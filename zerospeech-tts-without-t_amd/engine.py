@@ -24,7 +24,21 @@ def _half_up(t):
     return (t + 1) // 2
 
 
-class EncoderEngine(object):
+class _Taped(object):
+    """`tape` of an engine, one per micro-batch lane of its context (see layers.Ctx.lane)."""
+
+    @property
+    def tape(self):
+        return self._tapes.get(self.ctx.lane)
+
+    @tape.setter
+    def tape(self, tp):
+        if not hasattr(self, '_tapes'):
+            self._tapes = {}
+        self._tapes[self.ctx.lane] = tp
+
+
+class EncoderEngine(_Taped):
     def __init__(self, ctx, P, G, c_in, c_h1, c_h2, c_h3, enc_size, ns, dp, seg_len):
         """P / G: dicts name -> fp32 parameter / gradient tensors (reference state_dict names)."""
         self.ctx = ctx
@@ -220,7 +234,7 @@ class EncoderEngine(object):
                dact_ld=(dact.ld if dact is not None else 0), slope=self.ns, out=out.ptr(), ldo=out.ld, unshuffle=0)
 
 
-class DecoderEngine(object):
+class DecoderEngine(_Taped):
     def __init__(self, ctx, P, G, c_in, c_out, c_h, c_a, ns, seg_len, output_mask=False):
         self.ctx = ctx
         self.uid = _uid()
@@ -399,7 +413,7 @@ class DecoderEngine(object):
         for k in range(5):
             st_k = sts[k % len(sts)].cuda_stream if sts is not None else c.stream
             L.call('zs_emb_scatter', 'ZsEmbScatter', st_k, emb_sum=L.ptr(self._embsum, k * B * ch), emb_ld=ch,
-                   idx=L.ptr(tp['cidx']), B=B, demb=L.ptr(self.gemb[k]), demb_ld=ch, n_rows=self.n_spk, C=ch, accumulate=0)
+                   idx=L.ptr(tp['cidx']), B=B, demb=L.ptr(self.gemb[k]), demb_ld=ch, n_rows=self.n_spk, C=ch, accumulate=int(c.accumulate))
         bits = tp['bits']
         self.input_emb.wgrad(dx, bits)
         dbits = None
@@ -409,7 +423,7 @@ class DecoderEngine(object):
         return dbits
 
 
-class ClassifierEngine(object):
+class ClassifierEngine(_Taped):
     """SpeakerClassifier.forward (reference model/model.py:262-280) and its backward: four conv blocks on the
     T' = T/8 code sequence (conv k5/k3 + lrelu, InstanceNorm, Dropout, identity residual on blocks 2 and 3) and a
     final un-padded Conv1d whose kernel spans the whole sequence (k = seg_len/8) -> logits [B, n_class]."""

@@ -127,6 +127,17 @@ def check_status(device):
                         (' and '.join(n for b, n in ((1, 'forward'), (2, 'BPTT')) if v & b), v))
 
 
+_LANE = {}
+
+
+def lane_stream(device, i):
+    """Stream of micro-batch lane i >= 1 (lane 0 runs on the caller's stream)."""
+    key = (device.type, device.index, i)
+    if key not in _LANE:
+        _LANE[key] = torch.cuda.Stream(device)
+    return _LANE[key]
+
+
 _COPY = {}
 
 
@@ -155,6 +166,11 @@ class Ctx(object):
         self._bufs = {}
         self._ws = None
         self.hooks = {}              # capture-time hooks of the engines (name -> callable or None)
+        # micro-batch lanes (trainer.AEStep): a lane has its own activation buffers and tape; the second lane ADDS its parameter
+        # gradients to the first one's (same side stream per layer: stream order makes the sum deterministic)
+        self.lane = ''
+        self.accumulate = False
+        self.pin_wgrad_streams = False   # lanes: a layer's weight gradients always go to the same side stream
         # sticky status word of the persistent kernels (ZsGruFwd.status): OR-ed into on a bounded-spin timeout, never cleared by
         # the library; read at the host's own sync points by check_status()
         self.status = device_status(self.device)
@@ -167,7 +183,7 @@ class Ctx(object):
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def raw(self, name, n, dtype, zero=True):
-        key = (name, n, dtype)
+        key = (self.lane, name, n, dtype)
         t = self._bufs.get(key)
         if t is None:
             t = torch.zeros(n + SLACK, dtype=dtype, device=self.device)
@@ -218,6 +234,7 @@ class ConvLayer(object):
         self.wf = torch.zeros(self.n_pad * self.ldw + SLACK, dtype=tdt, device=dev)
         self.wd = torch.zeros(self.n_pad_d * self.ldw_d + SLACK, dtype=tdt, device=dev)
         self.bias_p = torch.zeros(self.Cout, dtype=torch.float32, device=dev) if (split2 and bias is not None) else None
+        self.sid = next_sid()          # the side stream this layer's weight gradients always use
 
     def pack(self):
         c = self.ctx
@@ -287,11 +304,21 @@ class ConvLayer(object):
         kw = dict(dtype=c.dt, dY=dY.ptr(), ldy=dY.ld, y_cols=y_cols, X=X.ptr(), ldx=X.ld, x_batch_stride=X.T * X.ld,
                   x_cols=x_cols, B=X.B, T_in=X.T, T_out=dY.T, taps=self.k, stride=self.stride, pad_left=self.pad_l,
                   pad_mode=self.pad_mode, Cout=self.Cout, Cin=self.Cin, dW=L.ptr(self.gw), so=self.so, si=self.si, sj=self.sj,
-                  db=(L.ptr(self.gb) if bias else None), co_split2=int(self.split2), accumulate=int(accumulate), splits=0)
-        wgrad_call(c, kw)
+                  db=(L.ptr(self.gb) if bias else None), co_split2=int(self.split2), accumulate=int(accumulate or c.accumulate), splits=0)
+        wgrad_call(c, kw, self.sid)
 
 
-def wgrad_call(ctx, kw):
+_SID = [0]
+
+
+def next_sid():
+    _SID[0] += 1
+    return _SID[0]
+
+
+def wgrad_call(ctx, kw, sid=None):
+    """sid: None = round robin over the side streams; an int pins the call to side stream sid % N (every weight gradient of one
+    parameter on ONE stream: with micro-batch lanes the second lane's accumulating launch is ordered behind the first's)."""
     S = L.STRUCTS['ZsGemmWgrad']
     s = S()
     for k, v in kw.items():
@@ -303,8 +330,11 @@ def wgrad_call(ctx, kw):
         # ordered after everything enqueued so far on the main stream (dY and X are complete), then asynchronous;
         # the weight gradients of one side stream serialise, so they share that stream's split-K workspace
         sd = side_stream(ctx.device)
-        i = sd['next']                                   # plain round robin (measured: 1 stream 13.7 ms/step, 3: 13.5, 4: 13.0,
-        sd['next'] = (i + 1) % len(sd['streams'])        # 8: 13.05; big GEMMs pinned to one stream: 13.55)
+        if sid is not None and ctx.pin_wgrad_streams:
+            i = sid % len(sd['streams'])
+        else:
+            i = sd['next']                               # plain round robin (measured: 1 stream 13.7 ms/step, 3: 13.5, 4: 13.0,
+            sd['next'] = (i + 1) % len(sd['streams'])    # 8: 13.05; big GEMMs pinned to one stream: 13.55)
         ws = sd['ws'][i]
         if ws is None or ws.numel() < need:
             # growth (first steps only): every side stream gets a workspace of the new size, so that no later launch --
@@ -342,6 +372,7 @@ class GruLayer(object):
         self.gb_hh = [G[prefix + 'bias_hh_l0' + s] for s in sfx]
         self.H = self.w_hh[0].shape[1]
         self.Cin = self.w_ih[0].shape[1]
+        self.sids = [next_sid() for _ in range(4)]
         H, Cin = self.H, self.Cin
         if H % 8:
             raise ValueError('GRU hidden size must be a multiple of 8 (got %d)' % H)
@@ -429,12 +460,12 @@ class GruLayer(object):
                                ldx=out.ld, x_batch_stride=T * out.ld, x_cols=H, B=B, T_in=T, T_out=T, taps=1, stride=1,
                                pad_left=(1 if d == 0 else -1), pad_mode=L.ZS_PAD_ZERO, Cout=3 * H, Cin=H,
                                dW=L.ptr(self.gw_hh[d]), so=H, si=1, sj=0, db=L.ptr(self.gb_hh[d]), co_split2=0,
-                               accumulate=0, splits=0))
+                               accumulate=int(c.accumulate), splits=0), self.sids[2 * d])
             wgrad_call(c, dict(dtype=c.dt, dY=dgi.ptr(3 * H * d), ldy=dgi.ld, y_cols=3 * H, X=X.ptr(), ldx=X.ld,
                                x_batch_stride=T * X.ld, x_cols=min(X.cols, rup(self.Cin, 16 // c.es)), B=B, T_in=T, T_out=T,
                                taps=1, stride=1, pad_left=0, pad_mode=L.ZS_PAD_ZERO, Cout=3 * H, Cin=self.Cin,
                                dW=L.ptr(self.gw_ih[d]), so=self.Cin, si=1, sj=0, db=L.ptr(self.gb_ih[d]), co_split2=0,
-                               accumulate=0, splits=0))
+                               accumulate=int(c.accumulate), splits=0), self.sids[2 * d + 1])
         kw = dict(dtype=c.dt, A=dgi.ptr(), lda=dgi.ld, a_batch_stride=T * dgi.ld, B=B, T_in=T, T_out=T, taps=1, stride=1,
                   pad_left=0, pad_mode=L.ZS_PAD_ZERO, gather=0, cin_pad=self.g6_pad, W=L.ptr(self.wih_d), ldw=self.ih_ldw_d,
                   N=self.Cin, n_pad=self.ih_npad_d, act=L.ZS_ACT_NONE, out=dX.ptr(), ldc=dX.ld,
