@@ -89,7 +89,7 @@ class EncoderEngine(_Taped):
                dst_f32=0, col_off=0, rows=B * T, cols=F, fill_cols=xin.ld, act=L.ZS_ACT_NONE)
         L.call('zs_cast_rows', 'ZsCastRows', st, dtype=c.dt, src=L.ptr(x), ld_src=F, src_f32=1, dst=cat.ptr(), ld_dst=cat.ld,
                dst_f32=0, col_off=7 * c1, rows=B * T, cols=F, fill_cols=cat.ld - 7 * c1, act=LRELU, slope=ns)   # :445-446
-        if c.overlap_wgrad and B * T >= 4096:
+        if c.overlap_wgrad and B * T >= 4096 and not (c.lane and os.environ.get('ZS_LANE_BANK_FORK', '0') != '1'):
             # the seven bank convs are independent and each fills half the chip at most (N = 128): run them side by side
             sts = fork_side(c.device)
             for i, l in enumerate(self.conv1s):                                                               # :441-444
