@@ -289,6 +289,10 @@ def resynth_main(args):
     n_utt = len(lens_all)
     value = n_utt * args.steps / dt
     gl = sum(gl_ms) / len(gl_ms) * 1e-3
+    gl_traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'r02_resynth_pmc_traffic.json')
+    if os.path.exists(tpath) and args.utts == 64:
+        gl_traffic = json.load(open(tpath)).get('kernels', {}).get('gl_iter_kernel<false>', {}).get('traffic_bytes_per_launch')
     fl = out_frames * (2 * n_iter + 1) * 2.5 * 1024 * 10          # per rank-0 shard
     out = {'metric': 'utterances/sec (test_encode + Griffin-Lim resynthesis, 64 utterances of 200..700 frames, n_iter=300)',
            'value': value, 'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -299,7 +303,7 @@ def resynth_main(args):
                                   'fragmenting and copies included' % (n_iter, len(lens)), 'parallelism': 'replicas%d' % world},
            'frames_per_s': float(sum(lens_all)) * args.steps / dt, 'encode_decode_ms': 1e3 * dt_enc, 'griffin_lim_ms': 1e3 * gl,
            'roofline': {'bound': 'fft-latency (fp32 vector peak as the ceiling)', 'achieved': fl / gl / 1e12, 'peak': 157.3, 'unit': 'TFLOP/s',
-                        'frac': fl / gl / 1e12 / 157.3, 'traffic': None,
+                        'frac': fl / gl / 1e12 / 157.3, 'traffic': gl_traffic, 'traffic_unit': 'bytes/launch (committed rocprofv3 --pmc passes of this command)',
                         'kernel': 'gl_iter_kernel (one fused Griffin-Lim iteration per launch, %d launches per batch)' % (n_iter + 1),
                         'avg_launch_ms': 1e3 * gl / (n_iter + 1), 'algorithmic_flop_per_launch': fl / (2 * n_iter + 1) * 2}}
     if not args.no_cpu_baseline:
@@ -442,7 +446,7 @@ def main():
     }
     peak = 2500.0 if args.dtype == 'bf16' else 157.3
     traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    tpath = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
     if args.dtype == 'bf16' and B == 256 and os.path.exists(tpath):
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); counters cannot be read from inside the process

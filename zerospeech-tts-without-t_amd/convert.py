@@ -273,17 +273,46 @@ def encode_batch(specs, trainer, seg_len, decode_speakers=None, noise_fn=None, m
         by_len.setdefault(it[3] - it[2], []).append(it)
     enc_out, dec_out = {}, {}
     pending = []                                          # (chunk, device encodings, device spectrograms): one host sync at the end
-    for Tf, group in sorted(by_len.items()):
-        for lo in range(0, len(group), max_batch):
-            chunk = group[lo:lo + max_batch]
-            x = torch.from_numpy(np.stack([padded[u][a:b] for (u, _, a, b, _) in chunk])).to(dev, non_blocking=True)   # [n, Tf, 513]
-            G = noise_fn(len(chunk), ((((Tf + 1) // 2 + 1) // 2) + 1) // 2, enc.enc_size) if noise_fn is not None else None
-            act, _ = enc(x.permute(0, 2, 1), G=G)
-            xd = None
-            if decode_speakers is not None:
-                c = torch.tensor([decode_speakers[u] for (u, _, _, _, _) in chunk], dtype=torch.int64).to(dev, non_blocking=True)
-                xd = dec(act, c).permute(0, 2, 1).contiguous()
-            pending.append((chunk, act.permute(0, 2, 1).contiguous(), xd))
+    # The fragment rule leaves ~60 distinct tail lengths, each its own small batch whose time is the latency of its GRU
+    # recurrences (T steps of ~6 us, a few workgroups wide): the length groups go round robin over ZS_INFER_STREAMS streams, each
+    # with its own activation buffers (layers.Ctx.lane), so several recurrences are in flight at once.  The largest group (the
+    # full seg_len fragments, up to max_batch rows: a chip-wide GRU grid) runs first, alone.
+    from . import layers
+    n_streams = max(1, int(os.environ.get('ZS_INFER_STREAMS', '4')))
+    main = torch.cuda.current_stream(dev)
+    streams = [main] + [layers.lane_stream(dev, 100 + i) for i in range(1, n_streams)]
+    ctxs = [enc._engine().ctx, dec._engine().ctx]
+    groups = sorted(by_len.items(), key=lambda kv: -len(kv[1]))
+    ev0 = torch.cuda.Event()
+    gi = 0
+    try:
+        for Tf, group in groups:
+            for lo in range(0, len(group), max_batch):
+                chunk = group[lo:lo + max_batch]
+                k = 0 if (gi == 0 or n_streams == 1) else 1 + (gi - 1) % (n_streams - 1)
+                if gi == 1:                               # the small groups start once the big one has been issued
+                    ev0.record(main)
+                    for s in streams[1:]:
+                        s.wait_event(ev0)
+                gi += 1
+                for cx in ctxs:
+                    cx.lane = '' if k == 0 else 'S%d' % k
+                with torch.cuda.stream(streams[k]):
+                    x = torch.from_numpy(np.stack([padded[u][a:b] for (u, _, a, b, _) in chunk])).to(dev, non_blocking=True)   # [n, Tf, 513]
+                    G = noise_fn(len(chunk), ((((Tf + 1) // 2 + 1) // 2) + 1) // 2, enc.enc_size) if noise_fn is not None else None
+                    act, _ = enc(x.permute(0, 2, 1), G=G)
+                    xd = None
+                    if decode_speakers is not None:
+                        c = torch.tensor([decode_speakers[u] for (u, _, _, _, _) in chunk], dtype=torch.int64).to(dev, non_blocking=True)
+                        xd = dec(act, c).permute(0, 2, 1).contiguous()
+                    pending.append((chunk, act.permute(0, 2, 1).contiguous(), xd))
+    finally:
+        for cx in ctxs:
+            cx.lane = ''
+    for s in streams[1:]:
+        ev = torch.cuda.Event()
+        ev.record(s)
+        main.wait_event(ev)
     for chunk, e_dev, xd_dev in pending:
         e = e_dev.cpu().numpy()
         xd = xd_dev.cpu().numpy() if xd_dev is not None else None
