@@ -16,7 +16,9 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .layers import Act, ConvLayer, Ctx, rup
+import os
+
+from .layers import Act, ConvLayer, Ctx, join_side, rup
 from .model import ZsModule
 
 LRELU = L.ZS_ACT_LRELU
@@ -120,7 +122,10 @@ class PatchEngine(object):
         _UID[0] += 1
         self.uid = _UID[0]
         self.ctx = ctx
-        ctx.overlap_wgrad = False          # several weight gradients accumulate into one buffer per step: keep them stream-ordered
+        # several weight gradients accumulate into one buffer per step (real / fake / penalty passes): every layer's weight
+        # gradients are pinned to ONE side stream, so stream order is the summation order (ZS_PATCH_OVERLAP=0: all on the main stream)
+        ctx.overlap_wgrad = os.environ.get('ZS_PATCH_OVERLAP', '1') == '1'
+        ctx.pin_wgrad_streams = True
         self.ns, self.dp, self.n_class = float(ns), float(dp), n_class
         self.pad_mode = L.ZS_PAD_REFLECT if seg_len >= 64 else L.ZS_PAD_ZERO
         self.G = G
@@ -157,6 +162,7 @@ class PatchEngine(object):
 
     def flush_grads(self):
         """End of a step: virtual weight gradients -> the parameters' gradient views (reference layouts)."""
+        join_side(self.ctx.device)                      # the side-stream weight gradients of this step
         for c in self.convs:
             c.flush()
         for h in (self.head_val, self.head_clf):
