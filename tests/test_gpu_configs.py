@@ -124,11 +124,14 @@ def test_config2_b256_bf16_default_dispatch_spot_checks(dev):
         got.append(float(o_r[m, ci])); ref.append(float(prod.sum())); absref.append(float(prod.abs().sum()))
     _check('dense2 data gradient (p8m16)', got, ref, absref, True)
 
-    # ---- (4) gemm_wgrad_p8: dense5.weight [1024, 3072] = dz5^T cat3 over M = 32768 rows
+    # ---- (4) gemm_wgrad_p8: dense5.weight[:, :2048] = dz5^T cat[out, rnn] over M = 32768 rows; the third column block (the
+    #          broadcast emb5 of append_emb, model/model.py:357) is folded into a per-speaker bias: its gradient is
+    #          sum_b (sum_t dz5[b, t, co]) * emb5[c_b, ci], computed from bf16-rounded column sums (tolerance 2^-8 of sum|terms|)
     dz5 = de.ctx.act('d_dz5' + tag, B, T, ch)
     cat3 = tp['cat3']
+    assert cat3.C == 2 * ch
     gw = dec.grad_view('dense5.weight')
-    cos, cis = rng.randint(ch, size=n_chk), rng.randint(3 * ch, size=n_chk)
+    cos, cis = rng.randint(ch, size=n_chk), rng.randint(2 * ch, size=n_chk)
     ycols = _rows(dz5)[:, torch.from_numpy(cos).to(dev)].double().cpu()          # [M, n_chk]
     xcols = _rows(cat3)[:, torch.from_numpy(cis).to(dev)].double().cpu()
     prod = ycols * xcols
@@ -137,6 +140,13 @@ def test_config2_b256_bf16_default_dispatch_spot_checks(dev):
     gb = dec.grad_view('dense5.bias')
     yb_ = _rows(dz5)[:, :ch].double().cpu()
     _check('dense5.bias gradient', gb.double().cpu().numpy(), yb_.sum(0).numpy(), yb_.abs().sum(0).numpy(), False)
+    s_b = _bf(_rows(dz5)[:, :ch].float().view(B, T, ch).sum(1)).cpu()            # [B, ch] per-sample column sums, as the kernel rounds them
+    e5 = _bf(dec.emb5.weight.detach())[c.cpu()].cpu()                            # [B, ch]
+    cos, cis = rng.randint(ch, size=n_chk), rng.randint(ch, size=n_chk)
+    terms = s_b[:, cos] * e5[:, cis]
+    got = gw[torch.from_numpy(cos), torch.from_numpy(2 * ch + cis)].double().cpu().numpy()
+    ref, aref = terms.sum(0).numpy(), terms.abs().sum(0).numpy()
+    assert (np.abs(got - ref) <= (2.0 ** -8) * aref + 1e-12).all(), 'dense5.weight[:, 2ch:] (folded emb5 block)'
 
     # ---- (5) gemm_wgrad_p8 with taps + reflect + split2 packing: conv5.weight [2048, 1024, 3]
     dza = de.ctx.act('d_dza2' + tag, B, Ti, 2 * ch)

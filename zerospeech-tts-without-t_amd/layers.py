@@ -217,7 +217,8 @@ class ConvLayer(object):
     """Conv1d [Cout,Cin,k] or Linear [Cout,Cin] (k=1) as packed MFMA operands.
     split2: output channels packed so that the epilogue can pixel-shuffle (see zs_amd.h)."""
 
-    def __init__(self, ctx, weight, bias, gweight, gbias, stride=1, split2=False, pad_mode=L.ZS_PAD_REFLECT, name='', padded=True):
+    def __init__(self, ctx, weight, bias, gweight, gbias, stride=1, split2=False, pad_mode=L.ZS_PAD_REFLECT, name='', padded=True,
+                 strides=None):
         self.ctx, self.name = ctx, name
         self.w, self.b, self.gw, self.gb = weight, bias, gweight, gbias
         self.Cout, self.Cin = weight.shape[0], weight.shape[1]
@@ -226,6 +227,8 @@ class ConvLayer(object):
         self.pad_l = self.k // 2 if padded else 0              # pad_layer(): (k//2, k//2 - 1 | k//2); plain nn.Conv1d: none
         self.pad_r = (self.k - 1 - self.k // 2) if padded else 0
         self.so, self.si, self.sj = (self.Cin * self.k, self.k, 1) if weight.dim() == 3 else (self.Cin, 1, 0)
+        if strides is not None:                           # a column block of a wider parameter (element strides of weight / gweight)
+            self.so, self.si, self.sj = strides
         kc = ctx.kc                                       # elements per 128-byte K chunk
         self.cin_pad, self.cout_pad = rup(self.Cin, kc), rup(self.Cout, kc)
         self.ldw, self.n_pad = self.k * self.cin_pad, rup(self.Cout, 128)
@@ -279,7 +282,7 @@ class ConvLayer(object):
         L.call('zs_gemm_conv', 'ZsGemmConv', c.stream, **kw)
         return T_out
 
-    def dgrad(self, dY, T_x, out, dact_src=None, slope=0.0, add_src=None):
+    def dgrad(self, dY, T_x, out, dact_src=None, slope=0.0, add_src=None, out_f32=False, add_f32=False):
         """dY: Act [B,T_y,Cout] (ld >= cout_pad).  out: Act with B*(T_x+pad_l+pad_r) rows (padded domain; equals the
         input gradient when k == 1).  Optional epilogue: *lrelu'(dact_src), +add_src (both only meaningful for k == 1)."""
         c = self.ctx
@@ -287,11 +290,12 @@ class ConvLayer(object):
         kw = dict(dtype=c.dt, A=dY.ptr(), lda=dY.ld, a_batch_stride=dY.T * dY.ld, B=dY.B, T_in=dY.T, T_out=Tp, taps=self.k,
                   stride=self.stride, pad_left=0, pad_mode=L.ZS_PAD_ZERO, gather=1, cin_pad=self.cout_pad,
                   W=L.ptr(self.wd), ldw=self.ldw_d, N=self.Cin, n_pad=self.n_pad_d, act=L.ZS_ACT_NONE, slope=slope,
-                  out=out.ptr(), ldc=out.ld, out_cols=min(out.cols, rup(self.Cin, 32)), store_mode=L.ZS_STORE_ROWS, groups=1)
+                  out=out.ptr(), ldc=out.ld, out_cols=min(out.cols, rup(self.Cin, 32)), store_mode=L.ZS_STORE_ROWS, groups=1,
+                  out_f32=int(out_f32))
         if dact_src is not None:
             kw.update(dact_src=dact_src.ptr(), dact_ld=dact_src.ld)
         if add_src is not None:
-            kw.update(add_src=add_src.ptr(), add_ld=add_src.ld, add_f32=0)
+            kw.update(add_src=add_src.ptr(), add_ld=add_src.ld, add_f32=int(add_f32))
         L.call('zs_gemm_conv', 'ZsGemmConv', c.stream, **kw)
         return Tp
 
