@@ -124,14 +124,14 @@ def test_config2_b256_bf16_default_dispatch_spot_checks(dev):
         got.append(float(o_r[m, ci])); ref.append(float(prod.sum())); absref.append(float(prod.abs().sum()))
     _check('dense2 data gradient (p8m16)', got, ref, absref, True)
 
-    # ---- (4) gemm_wgrad_p8: dense5.weight[:, :2048] = dz5^T cat[out, rnn] over M = 32768 rows; the third column block (the
-    #          broadcast emb5 of append_emb, model/model.py:357) is folded into a per-speaker bias: its gradient is
-    #          sum_b (sum_t dz5[b, t, co]) * emb5[c_b, ci], computed from bf16-rounded column sums (tolerance 2^-8 of sum|terms|)
+    # ---- (4) gemm_wgrad_p8: dense5.weight [1024, 3072] = dz5^T cat[out, rnn, emb5 x T] over M = 32768 rows (with ZS_FOLD_EMB5=1 the
+    #          third column block is a per-speaker bias: its gradient then comes from bf16-rounded per-sample column sums)
     dz5 = de.ctx.act('d_dz5' + tag, B, T, ch)
     cat3 = tp['cat3']
-    assert cat3.C == 2 * ch
     gw = dec.grad_view('dense5.weight')
-    cos, cis = rng.randint(ch, size=n_chk), rng.randint(2 * ch, size=n_chk)
+    ncol = cat3.C
+    assert ncol == (2 if de.fold5 else 3) * ch
+    cos, cis = rng.randint(ch, size=n_chk), rng.randint(ncol, size=n_chk)
     ycols = _rows(dz5)[:, torch.from_numpy(cos).to(dev)].double().cpu()          # [M, n_chk]
     xcols = _rows(cat3)[:, torch.from_numpy(cis).to(dev)].double().cpu()
     prod = ycols * xcols
@@ -140,13 +140,14 @@ def test_config2_b256_bf16_default_dispatch_spot_checks(dev):
     gb = dec.grad_view('dense5.bias')
     yb_ = _rows(dz5)[:, :ch].double().cpu()
     _check('dense5.bias gradient', gb.double().cpu().numpy(), yb_.sum(0).numpy(), yb_.abs().sum(0).numpy(), False)
-    s_b = _bf(_rows(dz5)[:, :ch].float().view(B, T, ch).sum(1)).cpu()            # [B, ch] per-sample column sums, as the kernel rounds them
-    e5 = _bf(dec.emb5.weight.detach())[c.cpu()].cpu()                            # [B, ch]
-    cos, cis = rng.randint(ch, size=n_chk), rng.randint(ch, size=n_chk)
-    terms = s_b[:, cos] * e5[:, cis]
-    got = gw[torch.from_numpy(cos), torch.from_numpy(2 * ch + cis)].double().cpu().numpy()
-    ref, aref = terms.sum(0).numpy(), terms.abs().sum(0).numpy()
-    assert (np.abs(got - ref) <= (2.0 ** -8) * aref + 1e-12).all(), 'dense5.weight[:, 2ch:] (folded emb5 block)'
+    if de.fold5:
+        s_b = _bf(_rows(dz5)[:, :ch].float().view(B, T, ch).sum(1)).cpu()        # [B, ch] per-sample column sums, as the kernel rounds them
+        e5 = _bf(dec.emb5.weight.detach())[c.cpu()].cpu()                        # [B, ch]
+        cos, cis = rng.randint(ch, size=n_chk), rng.randint(ch, size=n_chk)
+        terms = s_b[:, cos] * e5[:, cis]
+        got = gw[torch.from_numpy(cos), torch.from_numpy(2 * ch + cis)].double().cpu().numpy()
+        ref, aref = terms.sum(0).numpy(), terms.abs().sum(0).numpy()
+        assert (np.abs(got - ref) <= (2.0 ** -8) * aref + 1e-12).all(), 'dense5.weight[:, 2ch:] (folded emb5 block)'
 
     # ---- (5) gemm_wgrad_p8 with taps + reflect + split2 packing: conv5.weight [2048, 1024, 3]
     dza = de.ctx.act('d_dza2' + tag, B, Ti, 2 * ch)
@@ -563,3 +564,36 @@ def test_micro_batch_lanes_equal_the_single_chain(dev, dtype):
         runs.append((losses, enc.flat_params()[0].clone(), dec.flat_params()[0].clone(), sum(len(v['graphs']) for v in ae._graphs.values())))
     assert runs[0][3] == 1 and runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
     assert runs[0][0][-1] < runs[0][0][0]
+
+
+def test_folded_emb5_block_equals_the_literal_concatenation(dev, monkeypatch):
+    """ZS_FOLD_EMB5=1 (the third K block of the decoder's dense5 as a per-speaker bias) against the default
+    cat[out, rnn, emb5 x T] GEMM: output and every decoder gradient agree (fp32: 2e-5 of scale)."""
+    from zs_amd.model import Decoder
+    g = torch.Generator().manual_seed(9)
+    bits = (torch.rand(3, 8, 16, generator=g) > 0.5).float()
+    cidx = torch.randint(0, 4, (3,), generator=g)
+    dl = torch.randn(3, 128, 80, generator=g) * 1e-3
+    res = []
+    for fold in ('0', '1'):
+        monkeypatch.setenv('ZS_FOLD_EMB5', fold)
+        torch.manual_seed(1)
+        dec = Decoder(c_in=8, c_out=80, c_h=64, c_a=4, ns=0.01, seg_len=128, dtype='fp32').to(dev)
+        dec.train()
+        eng = dec._engine()
+        assert eng.fold5 == (fold == '1')
+        xd = dec(bits.to(dev), cidx.to(dev))
+        from zs_amd import _lib as L
+        dlog = eng.ctx.act('t_dl', 3, 128, 80)
+        L.call('zs_cast_rows', 'ZsCastRows', eng.ctx.stream, dtype=eng.ctx.dt, src=L.ptr(dl.to(dev).contiguous()), ld_src=80, src_f32=1,
+               dst=dlog.ptr(), ld_dst=dlog.ld, dst_f32=0, col_off=0, rows=3 * 128, cols=80, fill_cols=dlog.ld, act=L.ZS_ACT_NONE)
+        eng.backward(dlog)
+        from zs_amd.layers import join_side
+        join_side(dev)
+        torch.cuda.synchronize()
+        res.append((xd.clone(), {k: dec.grad_view(k).clone() for k, _ in dec.named_parameters()}))
+    assert (res[0][0] - res[1][0]).abs().max().item() < 2e-5
+    for k, ref in res[0][1].items():
+        scale = ref.abs().max().item()
+        if scale > 1e-8:
+            assert (res[1][1][k] - ref).abs().max().item() / scale < 2e-5, k

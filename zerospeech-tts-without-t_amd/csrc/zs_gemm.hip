@@ -1791,6 +1791,7 @@ struct Knob {
 Knob g_wgrad_p8("ZS_WGRAD_P8", 1);
 Knob g_wgrad_wgs("ZS_WGRAD_WGS", 256);      // workgroups one weight-gradient launch aims for (split-K plan of the 256x256 kernel)
 Knob g_wgrad_slab_cost("ZS_WGRAD_SLAB_COST", 13);   // cost of one split's slab write + re-read in K-tile times
+Knob g_wgrad_waste("ZS_WGRAD_P8_WASTE", 135);       // 256x256 weight-gradient tiles only while padded/real output area <= this / 100
 
 struct WgradPlan { int p8, splits, tile, co_tiles, ci_tiles, cout_r, cin_r, rows_per_split; };
 
@@ -1804,7 +1805,7 @@ WgradPlan wgrad_plan(const ZsGemmWgrad* p) {
   const int64_t t256 = (int64_t)((p->Cout + 255) / 256) * p->taps * ((p->Cin + 255) / 256);
   // padding waste of 256-wide tiles must stay small, and there must be enough K per workgroup to amortise the slab
   const double waste = (double)(((p->Cout + 255) / 256) * 256) * (((p->Cin + 255) / 256) * 256) / ((double)p->Cout * p->Cin);
-  w.p8 = wgrad_p8 && p->dtype == ZS_BF16 && waste <= 1.35 && M >= 2048 && (wgrad_p8 > 1 || t256 * M >= (int64_t)16 * 8192);
+  w.p8 = wgrad_p8 && p->dtype == ZS_BF16 && waste <= 0.01 * (double)g_wgrad_waste.get() && M >= 2048 && (wgrad_p8 > 1 || t256 * M >= (int64_t)16 * 8192);
   if (wgrad_p8 > 1 && p->dtype == ZS_BF16) w.p8 = 1;                   // forced (tests)
   w.tile = w.p8 ? 256 : 128;
   w.co_tiles = (p->Cout + w.tile - 1) / w.tile; w.ci_tiles = (p->Cin + w.tile - 1) / w.tile;
@@ -1932,6 +1933,7 @@ extern "C" int zs_set_option(const char* key, int value) {
   else if (key && !strcmp(key, "wgrad_p8")) slot = &g_wgrad_p8;
   else if (key && !strcmp(key, "wgrad_wgs")) slot = &g_wgrad_wgs;
   else if (key && !strcmp(key, "wgrad_slab_cost")) slot = &g_wgrad_slab_cost;
+  else if (key && !strcmp(key, "wgrad_p8_waste")) slot = &g_wgrad_waste;
   if (key && !strcmp(key, "gru_persist")) return zs_gru_persist_option(value);
   if (key && !strcmp(key, "gru_spin_limit")) return zs_gru_spin_limit_option(value);
   if (key && !strcmp(key, "gl_prefetch")) return zs_gl_prefetch_option(value);

@@ -254,16 +254,23 @@ class DecoderEngine(_Taped):
         # time: W5[:, 2ch:] . emb5[c_b] is a per-SPEAKER bias table (n_spk x ch, one tiny GEMM per step) added in the epilogue of the
         # GEMM over the first two blocks -- a third of this layer's forward, data-gradient and weight-gradient FLOPs (3.6 % of the
         # step's) and the broadcast copy of emb5 disappear; the two column blocks are ConvLayers over views of the one parameter.
+        # ZS_FOLD_EMB5=1 (measured 1 % SLOWER at B = 256 bf16: 11.96 vs 11.85 ms -- the per-sample bias takes the GEMM off its fast
+        # register epilogue and adds six small launches to the chain, more than the saved third of the layer is worth under the
+        # power cap; kept as a tested option)
+        self.fold5 = os.environ.get('ZS_FOLD_EMB5', '0') == '1'
         W5, gW5 = P['dense5.weight'], G['dense5.weight']
         st5 = (W5.stride(0), 1, 0)
-        self.dense5 = ConvLayer(ctx, W5[:, :2 * c_h], P['dense5.bias'], gW5[:, :2 * c_h], G['dense5.bias'], pad_mode=self.pad_mode,
-                                name='dense5', strides=st5)
-        self.dense5e = ConvLayer(ctx, W5[:, 2 * c_h:], None, gW5[:, 2 * c_h:], None, pad_mode=self.pad_mode, name='dense5e', strides=st5)
+        if self.fold5:
+            self.dense5 = ConvLayer(ctx, W5[:, :2 * c_h], P['dense5.bias'], gW5[:, :2 * c_h], G['dense5.bias'], pad_mode=self.pad_mode,
+                                    name='dense5', strides=st5)
+            self.dense5e = ConvLayer(ctx, W5[:, 2 * c_h:], None, gW5[:, 2 * c_h:], None, pad_mode=self.pad_mode, name='dense5e', strides=st5)
+        else:                                             # the literal cat[out, rnn, emb5 x T] GEMM (K = 3 c_h)
+            self.dense5, self.dense5e = mk('dense5'), None
         self.linear = mk('linear')
         self.emb = [P['emb%d.weight' % i] for i in range(1, 6)]
         self.gemb = [G['emb%d.weight' % i] for i in range(1, 6)]
         self.layers = [self.input_emb] + [l for p in self.convs for l in p] + [l for p in self.dense for l in p] + \
-            [self.dense5, self.dense5e, self.linear]
+            [self.dense5, self.linear] + ([self.dense5e] if self.fold5 else [])
         self.tape = None
 
     def pack(self):
@@ -296,7 +303,7 @@ class DecoderEngine(_Taped):
             stt = self._in(yb, xn, xen, nxt, cidx, L.ZS_RES_UPSAMPLE2, x, training, 'c%d' % i)
             tp['blocks'].append((x, xe, ya, s, yb, stt, T))
             x, xe, T = xn, xen, 2 * T
-        cat3 = c.act('d_cat3' + tag, B, T, 2 * ch)
+        cat3 = c.act('d_cat3' + tag, B, T, (2 if self.fold5 else 3) * ch)
         for j, (la, lb) in enumerate(self.dense):                                                        # :333-342, :350-351
             y1 = c.act('d_y1%d' % j + tag, B, T, ch)
             y1e = c.act('d_y1e%d' % j + tag, B, T, ch)
@@ -319,6 +326,12 @@ class DecoderEngine(_Taped):
         self.gru.fwd(xe, cat3, ch, gi, gates)                                                            # :352-356
         if post is not None:
             post()
+        if not self.fold5:
+            L.call('zs_add_rowvec', 'ZsAddRowvec', st, dtype=c.dt, x=None, vec=L.ptr(emb[4]), vec_ld=ch, idx=L.ptr(cidx),
+                   out=cat3.ptr(2 * ch), ldo=cat3.ld, B=B, T=T, C=ch, fill_cols=ch)                       # :357 append_emb
+            h5 = c.act('d_h5' + tag, B, T, ch)
+            self.dense5.fwd(cat3, out=h5, act=LRELU, slope=ns)
+            return self._fwd_tail(c, tp, h5, cat3, gates, xe, T, tag, B)
         # append_emb (:357) folded: pv[spk] = W5[:, 2ch:] . emb5[spk]  (fp32 table), added per sample in dense5's epilogue
         e5 = c.act('d_e5rows_%d' % self.uid, 1, self.n_spk, ch)
         L.call('zs_cast_rows', 'ZsCastRows', st, dtype=c.dt, src=L.ptr(emb[4]), ld_src=ch, src_f32=1, dst=e5.ptr(), ld_dst=e5.ld,
@@ -328,6 +341,9 @@ class DecoderEngine(_Taped):
         pv_t = pv.t[:self.n_spk * pv.ld].view(self.n_spk, pv.ld)
         h5 = c.act('d_h5' + tag, B, T, ch)
         self.dense5.fwd(cat3, out=h5, act=LRELU, slope=ns, pre_vec=pv_t, idx=cidx)                       # :358-359
+        return self._fwd_tail(c, tp, h5, cat3, gates, xe, T, tag, B)
+
+    def _fwd_tail(self, c, tp, h5, cat3, gates, xe, T, tag, B):
         xdec = c.act('d_xdec' + tag, B, T, self.F, dtype=torch.float32)
         self.linear.fwd(h5, out=xdec, act=self.out_act, out_f32=True)                                    # :360-364
         tp.update(cat3=cat3, gates=gates, gru_in=xe, h5=h5, T=T)
@@ -380,21 +396,24 @@ class DecoderEngine(_Taped):
         dz5 = c.act('d_dz5' + tag, B, T, ch)
         self.linear.dgrad(dlogit, T, dz5, dact_src=h5, slope=ns)
         self.dense5.wgrad(dz5, cat3)
-        dcat3 = c.act('d_dcat3' + tag, B, T, 2 * ch)
+        dcat3 = c.act('d_dcat3' + tag, B, T, (2 if self.fold5 else 3) * ch)
         self.dense5.dgrad(dz5, T, dcat3)
-        # the folded emb5 block: with s[b] = sum_t dz5[b, t, :]  (per-sample column sums, slot 5)
-        #   d emb5 (per sample, slot 4) += s[b] . W5[:, 2ch:]          d W5[:, 2ch:] (+)= sum_b s[b]^T emb5[c_b]
-        self._combine(Act(dz5.t, B, T, ch, dz5.ld), T, 0, 0, None, emb_i=5)
-        s32 = Act(self._embsum, B, 1, ch, ch, 5 * B * ch)
-        sT = c.act('d_s5' + tag, B, 1, ch)
-        L.call('zs_cast_rows', 'ZsCastRows', c.stream, dtype=c.dt, src=s32.ptr(), ld_src=ch, src_f32=1, dst=sT.ptr(), ld_dst=sT.ld,
-               dst_f32=0, col_off=0, rows=B, cols=ch, fill_cols=sT.ld, act=L.ZS_ACT_NONE)
-        slot4 = Act(self._embsum, B, 1, ch, ch, 4 * B * ch)
-        self.dense5e.dgrad(sT, 1, slot4, add_src=slot4, out_f32=True, add_f32=True)
-        e5b = c.act('d_e5b' + tag, B, 1, ch)
-        L.call('zs_add_rowvec', 'ZsAddRowvec', c.stream, dtype=c.dt, x=None, vec=L.ptr(self.emb[4]), vec_ld=ch, idx=L.ptr(tp['cidx']),
-               out=e5b.ptr(), ldo=e5b.ld, B=B, T=1, C=ch, fill_cols=e5b.ld)
-        self.dense5e.wgrad(sT, e5b)
+        if not self.fold5:
+            self._combine(dcat3.sub(2 * ch, ch), T, 0, 0, None, emb_i=4)                   # d emb5 via append_emb
+        else:
+            # the folded emb5 block: with s[b] = sum_t dz5[b, t, :]  (per-sample column sums, slot 5)
+            #   d emb5 (per sample, slot 4) += s[b] . W5[:, 2ch:]          d W5[:, 2ch:] (+)= sum_b s[b]^T emb5[c_b]
+            self._combine(Act(dz5.t, B, T, ch, dz5.ld), T, 0, 0, None, emb_i=5)
+            s32 = Act(self._embsum, B, 1, ch, ch, 5 * B * ch)
+            sT = c.act('d_s5' + tag, B, 1, ch)
+            L.call('zs_cast_rows', 'ZsCastRows', c.stream, dtype=c.dt, src=s32.ptr(), ld_src=ch, src_f32=1, dst=sT.ptr(), ld_dst=sT.ld,
+                   dst_f32=0, col_off=0, rows=B, cols=ch, fill_cols=sT.ld, act=L.ZS_ACT_NONE)
+            slot4 = Act(self._embsum, B, 1, ch, ch, 4 * B * ch)
+            self.dense5e.dgrad(sT, 1, slot4, add_src=slot4, out_f32=True, add_f32=True)
+            e5b = c.act('d_e5b' + tag, B, 1, ch)
+            L.call('zs_add_rowvec', 'ZsAddRowvec', c.stream, dtype=c.dt, x=None, vec=L.ptr(self.emb[4]), vec_ld=ch, idx=L.ptr(tp['cidx']),
+                   out=e5b.ptr(), ldo=e5b.ld, B=B, T=1, C=ch, fill_cols=e5b.ld)
+            self.dense5e.wgrad(sT, e5b)
         dgi = c.act('d_dgi' + tag, B, T, 6 * H)
         dgh = c.act('d_dgh' + tag, B, T, 6 * H)
         gp = c.act('d_gpA' + tag, B, T + 2, ch)
