@@ -77,6 +77,23 @@ __global__ void add_rowvec_kernel(const ZsAddRowvec p) {
   }
 }
 
+// broadcast form (x == null, append_emb): 8 columns = one 16-byte store per lane
+template <typename T>
+__global__ void add_rowvec_bcast8_kernel(const ZsAddRowvec p) {
+  const int groups = p.fill_cols / 8;
+  const int64_t total = (int64_t)p.B * p.T * groups;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / groups;
+    const int c0 = (int)(i - r * groups) * 8;
+    const int b = (int)(r / p.T);
+    const float* v = p.vec + p.idx[b] * p.vec_ld + c0;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (c0 + e < p.C) ? v[e] : 0.f;
+    store8<T>((T*)p.out + r * p.ldo + c0, o);
+  }
+}
+
 // ---- embedding scatter (fixed sample order, no atomics) ---------------------------------------------
 __global__ void emb_scatter_kernel(const ZsEmbScatter p) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -181,8 +198,21 @@ __global__ void l1_stage2_kernel(const float* partial, int n, float* out, double
 __global__ void sqnorm_stage1_kernel(const float* g, int64_t n, double* partial) {
   __shared__ double red[NTE / 64];
   double s = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float v = g[i]; s += (double)v * (double)v;
+  const int64_t n4 = ((((uintptr_t)g) & 15) == 0) ? (n >> 2) : 0;          // 16-byte loads, two in flight per lane
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + stride < n4; i += 2 * stride) {
+    const float4 a = g4[i], b = g4[i + stride];
+    s += (double)a.x * a.x + (double)a.y * a.y + (double)a.z * a.z + (double)a.w * a.w;
+    s += (double)b.x * b.x + (double)b.y * b.y + (double)b.z * b.z + (double)b.w * b.w;
+  }
+  for (; i < n4; i += stride) {
+    const float4 a = g4[i];
+    s += (double)a.x * a.x + (double)a.y * a.y + (double)a.z * a.z + (double)a.w * a.w;
+  }
+  for (int64_t k = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+    const float v = g[k]; s += (double)v * (double)v;
   }
   s = wave_sum_d(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -346,6 +376,10 @@ extern "C" int zs_cast_rows(const ZsCastRows* p, void* stream) {
 extern "C" int zs_add_rowvec(const ZsAddRowvec* p, void* stream) {
   ZS_REQUIRE(p && p->vec && p->idx && p->out && p->B > 0 && p->T > 0 && p->C > 0 && p->fill_cols >= p->C, "zs_add_rowvec: bad args");
   ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_add_rowvec: bad dtype");
+  if (!p->x && p->fill_cols % 8 == 0 && p->ldo % 8 == 0 && (((uintptr_t)p->out) & 15) == 0) {
+    ZS_DISPATCH(p->dtype, add_rowvec_bcast8_kernel, dim3(nblocks((int64_t)p->B * p->T * (p->fill_cols / 8), 4096)), dim3(NTE), stream, *p);
+    return zs_check_launch("zs_add_rowvec");
+  }
   ZS_DISPATCH(p->dtype, add_rowvec_kernel, dim3(nblocks((int64_t)p->B * p->T * p->fill_cols, 4096)), dim3(NTE), stream, *p);
   return zs_check_launch("zs_add_rowvec");
 }
