@@ -281,3 +281,34 @@ def test_batched_encode_resynthesis_64_utterances(cv, tmp_path):
     wavs = cv.spectrogram2wav_batch(decs[:16], n_iter=20, do_trim=False)
     for d, w in zip(decs[:16], wavs):
         assert w.shape == (200 * (d.shape[0] - 1),) and np.isfinite(w).all()
+
+
+def test_inference_graph_cache_replays_equal_the_eager_forward(cv, tmp_path):
+    """encode_batch without injected noise (the product path of --test / --test_encode): the first call runs every (batch,
+    length) group eagerly, the second captures a hipGraph per group, later calls replay them.  For every call: the decoded
+    spectrograms equal the eager Decoder applied to the encodings that call returned (the decoder is deterministic), the
+    encodings are bits, and the Gumbel noise is fresh at every call (reference: noise is drawn in eval mode too)."""
+    from zs_amd.hps import make_hps
+    from zs_amd.trainer import Trainer
+    torch.manual_seed(2)
+    hps = make_hps(enc_size=16, emb_size=32, n_speakers=4, n_target_speakers=2)
+    tr = Trainer(hps, None, 'targeted_residual', 'multilabel_binary', log_dir=str(tmp_path / 'log'), dtype='fp32')
+    rng = np.random.RandomState(1)
+    lens = [300, 300, 131, 520, 129, 9, 200]
+    specs = [np.clip(rng.rand(n, 513).astype(np.float32), 1e-8, 1) for n in lens]
+    spk = [1, 0, 3, 2, 1, 0, 2]
+    dev = tr.device
+    prev = None
+    for call in range(4):
+        encs, decs = cv.encode_batch(specs, tr, 128, decode_speakers=spk)
+        if call >= 2:
+            assert len(tr._infer_graphs.graphs) > 0
+        for u, (e, d) in enumerate(zip(encs, decs)):
+            assert set(np.unique(e)) <= {0.0, 1.0} and d.shape[1] == 513 and e.shape[0] * 8 == d.shape[0]
+        # utterance 2 (131 frames -> one 130-frame fragment): decode its returned bits eagerly
+        e = torch.from_numpy(encs[2].T[None]).to(dev)                       # [1, E, T']
+        xd = tr.Decoder(e, torch.tensor([spk[2]], device=dev))[0].T.cpu().numpy()
+        assert np.abs(xd - decs[2]).max() < 1e-6
+        if prev is not None:
+            assert any((a != b).any() for a, b in zip(prev, encs)), 'the Gumbel noise did not change between calls'
+        prev = encs
