@@ -380,7 +380,7 @@ class InferGraphs(object):
             g = torch.cuda.CUDAGraph()
             xs, cs = x_dev.clone(), (c_dev.clone() if c_dev is not None else None)
             stream.synchronize()
-            with torch.cuda.graph(g, stream=stream, capture_error_mode='thread_local'):
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):        # (captured on torch's side stream; replayed on ours)
                 bits_f32, xdec = self._forward(xs, cs, L.ptr(seed))
             ent = self.graphs[key] = {'g': g, 'x': xs, 'c': cs, 'bits': bits_f32, 'xdec': xdec}
         else:
