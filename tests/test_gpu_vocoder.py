@@ -283,13 +283,14 @@ def test_batched_encode_resynthesis_64_utterances(cv, tmp_path):
         assert w.shape == (200 * (d.shape[0] - 1),) and np.isfinite(w).all()
 
 
-def test_inference_graph_cache_replays_equal_the_eager_forward(cv, tmp_path):
+def test_inference_graph_cache_replays_equal_the_eager_forward(cv, tmp_path, monkeypatch):
     """encode_batch without injected noise (the product path of --test / --test_encode): the first call runs every (batch,
     length) group eagerly, the second captures a hipGraph per group, later calls replay them.  For every call: the decoded
     spectrograms equal the eager Decoder applied to the encodings that call returned (the decoder is deterministic), the
     encodings are bits, and the Gumbel noise is fresh at every call (reference: noise is drawn in eval mode too)."""
     from zs_amd.hps import make_hps
     from zs_amd.trainer import Trainer
+    monkeypatch.setenv('ZS_INFER_GRAPH', '1')                  # (off by default: slower on this stack, see convert.encode_batch)
     torch.manual_seed(2)
     hps = make_hps(enc_size=16, emb_size=32, n_speakers=4, n_target_speakers=2)
     tr = Trainer(hps, None, 'targeted_residual', 'multilabel_binary', log_dir=str(tmp_path / 'log'), dtype='fp32')

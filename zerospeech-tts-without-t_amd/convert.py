@@ -282,7 +282,10 @@ def encode_batch(specs, trainer, seg_len, decode_speakers=None, noise_fn=None, m
     main = torch.cuda.current_stream(dev)
     streams = [main] + [layers.lane_stream(dev, 100 + i) for i in range(1, n_streams)]
     ctxs = [enc._engine().ctx, dec._engine().ctx]
-    graphs = _infer_graphs(trainer) if os.environ.get('ZS_INFER_GRAPH', '1') == '1' else None
+    # ZS_INFER_GRAPH=1: replay a cached hipGraph per (stream, batch, length).  Off by default: measured SLOWER (151 vs 131 ms per
+    # 64-utterance batch) -- on this stack a graph launch does not run beside work on other streams, so the length groups'
+    # GRU recurrences serialise again and that costs more than the ~4000 Python launches save.
+    graphs = _infer_graphs(trainer) if os.environ.get('ZS_INFER_GRAPH', '0') == '1' else None
     groups = sorted(by_len.items(), key=lambda kv: -len(kv[1]))
     ev0 = torch.cuda.Event()
     gi = 0
