@@ -291,17 +291,6 @@ def encode_batch(specs, trainer, seg_len, decode_speakers=None, noise_fn=None, m
     groups = sorted(by_len.items(), key=lambda kv: -len(kv[1]))
     ev0 = torch.cuda.Event()
     gi = 0
-    # every fragment of the batch is staged in ONE pinned host buffer (kept on the trainer, grow-only): the per-group H2D copies
-    # are then truly asynchronous -- a copy from pageable memory blocks the host until the group's stream has drained
-    n_rows = sum((it[3] - it[2]) for it in items)
-    pin = getattr(trainer, '_infer_pin', None)
-    if pin is None or pin[0].numel() < n_rows * 513 or pin[1].numel() < len(items):
-        main.synchronize()
-        pin = trainer._infer_pin = (torch.empty(max(n_rows * 513, 1), dtype=torch.float32).pin_memory(),
-                                    torch.empty(max(len(items), 1), dtype=torch.int64).pin_memory())
-    else:
-        torch.cuda.synchronize(dev)                       # the previous call's copies out of the buffer
-    row0 = item0 = 0
     try:
         for Tf, group in groups:
             for lo in range(0, len(group), max_batch):
@@ -315,16 +304,8 @@ def encode_batch(specs, trainer, seg_len, decode_speakers=None, noise_fn=None, m
                 for cx in ctxs:
                     cx.lane = '' if k == 0 else 'S%d' % k
                 with torch.cuda.stream(streams[k]):
-                    nc = len(chunk)
-                    xh = pin[0][row0 * 513:(row0 + nc * Tf) * 513].view(nc, Tf, 513)                                # [n, Tf, 513], pinned
-                    for i, (u, _, a, b, _) in enumerate(chunk):
-                        xh[i].copy_(torch.from_numpy(padded[u][a:b]))
-                    row0 += nc * Tf
-                    ch = None
-                    if decode_speakers is not None:
-                        ch = pin[1][item0:item0 + nc]
-                        ch.copy_(torch.tensor([decode_speakers[u] for (u, _, _, _, _) in chunk], dtype=torch.int64))
-                    item0 += nc
+                    xh = torch.from_numpy(np.stack([padded[u][a:b] for (u, _, a, b, _) in chunk]))                  # [n, Tf, 513]
+                    ch = torch.tensor([decode_speakers[u] for (u, _, _, _, _) in chunk], dtype=torch.int64) if decode_speakers is not None else None
                     if noise_fn is None and graphs is not None:
                         e_dev, xd = graphs.run(k, streams[k], xh, ch)
                         pending.append((chunk, e_dev, xd))
