@@ -352,7 +352,7 @@ def main():
     torch.manual_seed(1234 + rank)
     enc = Encoder(ns=0.01, dp=0.5, enc_size=E, seg_len=seg_len, enc_mode='multilabel_binary', dtype=args.dtype).to(dev)
     dec = Decoder(ns=0.01, c_in=E, c_h=ch, c_a=nspk, seg_len=seg_len, dtype=args.dtype).to(dev)
-    if world > 1:                                      # identical initial weights on every rank
+    if world > 1 or parallel.multi_rank():             # identical initial weights on every rank
         for net in (enc, dec):
             dist.broadcast(net.flat_params()[0], src=0)
             net.mark_dirty()
@@ -443,6 +443,7 @@ def main():
         'config': {'workload': 'train_ae english hps seg_len=128 enc_size=1024 emb_size=1024 n_speakers=102 F=513, batch=%d/GPU, '
                                'dropout+Gumbel on, fwd+bwd+clip+Adam' % B, 'global_batch': B * world, 'parallelism': 'dp%d' % world},
         'final_loss': loss, 'host_input': bool(args.host_input), 'host_enqueue_ms_per_step': 1e3 * t_host / args.steps, 'hipgraph': bool(ae.use_graph and (world == 1 or os.environ.get('ZS_GRAPH_MULTI', '1') == '1')),
+        'graph_segments': sum(len(v['graphs']) for v in ae._graphs.values()) if ae._graphs else None,
     }
     peak = 2500.0 if args.dtype == 'bf16' else 157.3
     traffic = None

@@ -17,7 +17,7 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get('ZS_FORCE_MULTI') == '1') and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -30,6 +30,12 @@ def init_from_env(backend=None):
 
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def multi_rank():
+    """True when the data-parallel code path is to be taken: more than one rank, or ZS_FORCE_MULTI=1 (a one-rank rehearsal of the
+    multi-rank step -- three hipGraphs with RCCL all-reduces between them -- on a single GPU)."""
+    return world_size() > 1 or (os.environ.get('ZS_FORCE_MULTI') == '1' and dist.is_available() and dist.is_initialized())
 
 
 def rank():
@@ -61,8 +67,7 @@ class GradReducer(object):
         return 1.0 / world_size()
 
     def start(self, flat):
-        w = world_size()
-        if w == 1:
+        if not multi_rank():
             return
         n = flat.numel()
         if self.bf16:

@@ -192,7 +192,7 @@ class AEStep(object):
         Returns the device scalar holding loss_rec."""
         enc, dec = self.Encoder, self.Decoder
         enc.train(); dec.train()
-        multi = parallel.world_size() > 1
+        multi = parallel.multi_rank()
         plain = noise is None and drop_masks is None and seed is None and update
         # multi-rank: three graphs with the all-reduces launched between them (ZS_GRAPH_MULTI=0: every launch from the host)
         if plain and self.use_graph and (not multi or os.environ.get('ZS_GRAPH_MULTI', '1') == '1'):
@@ -473,7 +473,7 @@ class HostFedStep(object):
 
     def __next__(self):
         ae = self.ae
-        multi = parallel.world_size() > 1
+        multi = parallel.multi_rank()
         c, x = self._next
         if self.P is None:
             self._alloc(c, x)
@@ -593,7 +593,7 @@ class ClfStep(object):
         ce, out = self._classify(logits, c, -float(alpha), seed + 1, clf_masks)          # maximise the classification loss
         dbits = de.backward(dlogit)
         dx = ce.backward(self._dl, out.ld, need_dx=True, param_grads=False)
-        multi = parallel.world_size() > 1
+        multi = parallel.multi_rank()
         if multi:
             join_side(self.device)
             ae.reducer.start(dec.flat_params()[1])
