@@ -239,7 +239,7 @@ def resynth_main(args):
     gl_ms = []
 
     def run(timed):
-        encs, decs = cv.encode_batch(specs, tr, 128, decode_speakers=spk)
+        encs, decs = cv.encode_batch(specs, tr, 128, decode_speakers=spk, to_host=False)      # spectrograms stay on the device
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         orig = cv.griffin_lim_batch
 
@@ -311,7 +311,7 @@ def resynth_main(args):
         import zs_oracle as O      # CPU baseline beside the measurement only
         cores = cpu_share()
         torch.set_num_threads(cores)
-        d = np.asarray(decs[int(np.argmin([abs(x.shape[0] - 376) for x in decs]))], dtype=np.float32)
+        d = np.asarray(decs[int(np.argmin([abs(x.shape[0] - 376) for x in decs]))].cpu(), dtype=np.float32)
         t0 = time.perf_counter()
         O.spectrogram2wav(d, n_iter=n_iter)
         dc = time.perf_counter() - t0
@@ -319,7 +319,7 @@ def resynth_main(args):
                                'sample': 'oracle spectrogram2wav (Griffin-Lim n_iter=%d, numpy FFT) of ONE %d-frame utterance: %.2f s; the '
                                          'network forward is not included (the vocoder is >95 %% of the CPU path)' % (n_iter, d.shape[0], dc)}
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
@@ -473,7 +473,7 @@ def main():
             big = cpu_baseline(seg_len, F, E, ch, nspk, steps=1, batch=B)              # and the GPU configuration's
             out['cpu_baseline']['at_gpu_batch'] = {k: big[k] for k in ('value', 'unit', 'sample')}
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -281,6 +281,15 @@ def test_batched_encode_resynthesis_64_utterances(cv, tmp_path):
     wavs = cv.spectrogram2wav_batch(decs[:16], n_iter=20, do_trim=False)
     for d, w in zip(decs[:16], wavs):
         assert w.shape == (200 * (d.shape[0] - 1),) and np.isfinite(w).all()
+    # device-resident hand-over (encode_batch(to_host=False) -> spectrogram2wav_batch): same spectrograms, same waveforms
+    store.clear()
+    encs_d, decs_d = cv.encode_batch(specs, tr, 128, decode_speakers=spk, noise_fn=noise_fn, to_host=False)
+    assert all(torch.is_tensor(d) and d.is_cuda for d in decs_d)
+    for e, e2, d, d2 in zip(encs, encs_d, decs, decs_d):
+        assert (e == e2).all() and np.array_equal(d, d2.cpu().numpy())
+    wavs_d = cv.spectrogram2wav_batch(decs_d[:16], n_iter=20, do_trim=False)
+    for w, w2 in zip(wavs, wavs_d):
+        assert np.array_equal(w, w2)
 
 
 @pytest.mark.parametrize('mode', ['plan', 'graph'])

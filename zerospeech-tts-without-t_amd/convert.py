@@ -118,12 +118,17 @@ def spectrogram2wav_batch(mags_tf, n_iter=None, do_trim=True):
     D2H copy; only librosa.effects.trim (restated) runs per utterance on the host."""
     dev = _device()
     st = torch.cuda.current_stream(dev).cuda_stream
-    lens = [int(np.shape(m)[0]) for m in mags_tf]
+    lens = [int(m.shape[0]) for m in mags_tf]
     n, Tm = len(lens), max(lens)
-    host = np.zeros((n, Tm, 513), dtype=np.float32)
-    for i, m in enumerate(mags_tf):
-        host[i, :lens[i]] = np.asarray(m, dtype=np.float32)
-    t = torch.from_numpy(host).to(dev)
+    if all(torch.is_tensor(m) and m.is_cuda for m in mags_tf):          # decoder outputs still on the device (encode_batch(to_host=False))
+        t = torch.zeros(n, Tm, 513, dtype=torch.float32, device=dev)
+        for i, m in enumerate(mags_tf):
+            t[i, :lens[i]] = m
+    else:
+        host = np.zeros((n, Tm, 513), dtype=np.float32)
+        for i, m in enumerate(mags_tf):
+            host[i, :lens[i]] = np.asarray(m.cpu() if torch.is_tensor(m) else m, dtype=np.float32)
+        t = torch.from_numpy(host).to(dev)
     amp = torch.empty_like(t)
     L.check(L.lib().zs_gl_denormalize(L.ptr(t), L.ptr(amp), t.numel(), st), 'zs_gl_denormalize')     # convert.py:56-58
     wav, lengths, lens = griffin_lim_batch(None, n_iter=n_iter, device=dev, mag_padded=(amp, lens))
@@ -249,12 +254,13 @@ def encode(src_speaker_spec, trainer, seg_len, s_speaker=None, utt_id=None, resu
         return encodings
 
 
-def encode_batch(specs, trainer, seg_len, decode_speakers=None, noise_fn=None, max_batch=256):
+def encode_batch(specs, trainer, seg_len, decode_speakers=None, noise_fn=None, max_batch=256, to_host=True):
     """Batched encode()/convert() for many utterances: the same fragments the reference would send through the
     network one by one (convert.py:151-165) are grouped by length and run as batches on the GPU.
     specs: list of [T_i, 513] arrays.  decode_speakers: optional list of target speaker ids -> also returns the decoded
     spectrograms (enc_only path of convert()).  noise_fn(n_frag, T', E) -> Gumbel noise [n, T', E, 2] or None makes the
-    stochastic discretiser reproducible.  Returns (encodings list, decoded list or None)."""
+    stochastic discretiser reproducible.  Returns (encodings list, decoded list or None); to_host=False leaves the decoded
+    spectrograms on the device (torch tensors [T_out, 513]) for spectrogram2wav_batch."""
     trainer.set_eval()
     enc, dec = trainer.Encoder, trainer.Decoder
     dev = trainer.device
@@ -329,7 +335,7 @@ def encode_batch(specs, trainer, seg_len, decode_speakers=None, noise_fn=None, m
         main.wait_event(ev)
     for chunk, e_dev, xd_dev in pending:
         e = e_dev.cpu().numpy()
-        xd = xd_dev.cpu().numpy() if xd_dev is not None else None
+        xd = (xd_dev.cpu().numpy() if to_host else xd_dev) if xd_dev is not None else None
         for i, (u, k, _, _, trunc) in enumerate(chunk):
             enc_out[(u, k)] = e[i][:trunc] if trunc is not None else e[i]
             if xd is not None:
@@ -341,7 +347,8 @@ def encode_batch(specs, trainer, seg_len, decode_speakers=None, noise_fn=None, m
         ks = sorted(k for (uu, k) in enc_out if uu == u)
         encs.append(np.concatenate([enc_out[(u, k)] for k in ks], axis=0))
         if decs is not None:
-            decs.append(np.concatenate([dec_out[(u, k)] for k in ks], axis=0))
+            parts = [dec_out[(u, k)] for k in ks]
+            decs.append(np.concatenate(parts, axis=0) if to_host else (parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)))
     return encs, decs
 
 
