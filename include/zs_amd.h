@@ -64,7 +64,7 @@ int zs_set_option(const char* key, int value);
  *                                          s/stride < T_in, else a zero row.
  * Replaces: pad_layer()+nn.Conv1d (model/model.py:20-40), linear() (model/model.py:69-78), the GRU
  * input/recurrent products of nn.GRU (model/model.py:59-66), and their autograd data gradients.
- * Epilogue order: +bias[n] -> +pre_vec[vec_idx[b]][n] -> act -> *lrelu'(dact_src[m][n]) ->
+ * Epilogue order: +bias[n] -> +pre_vec[vec_idx[b]][n] -> act (-> colsum) -> *lrelu'(dact_src[m][n]) ->
  *                 +add_src[m][n] -> store out (-> out2 = value + vec2[vec_idx[b]][col]).
  * ZS_STORE_SPLIT2 realises pixel_shuffle_1d (model/model.py:43-51) for weights whose output
  * channels were packed as n' = r*(N/2) + c:  (m, n') -> row 2m + (n' >= N/2), col n' mod (N/2).
@@ -89,6 +89,11 @@ typedef struct {
   void* out2; int64_t ldc2; int32_t out2_cols; int32_t store_mode2;
   const float* vec2; int64_t vec2_ld;
   int32_t groups; int64_t a_gstride, w_gstride, out_gstride, bias_gstride;
+  /* optional per-sample column sums of the value BEFORE dact_src / add_src (the per-sample part of nn.Embedding's backward
+   * where an embedding row was added to this GEMM's input, model/model.py:319,336,353; finished by zs_emb_scatter):
+   *   colsum[b][n - colsum_col0] += sum_t value[b*T_out + t][n]      for colsum_col0 <= n < N
+   * One owner per (b, n): plain read-modify-write, no atomics.  Needs T_out | 128 (whole samples per tile). */
+  float* colsum; int64_t colsum_ld; int32_t colsum_col0;
 } ZsGemmConv;
 int zs_gemm_conv(const ZsGemmConv* p, void* stream);
 
@@ -140,6 +145,14 @@ typedef struct {
 int zs_pack_weight(const ZsPackWeight* p, void* stream);
 /* the same for n jobs (one dtype) in ceil(n/32) launches: the per-step repack of a whole net after the optimiser step */
 int zs_pack_weight_batch(const ZsPackWeight* jobs, int32_t n, void* stream);
+
+/* zs_copy_vec_batch: n small fp32 vector copies in ONE launch, dst[i*dst_stride] = src[i*src_stride] for i < len: the bias
+ * re-ordering that goes with the pixel-shuffle packing (co_split2) and the stacked nn.GRU biases, issued with the re-pack. */
+typedef struct {
+  const float* src; float* dst;
+  int32_t len, src_stride, dst_stride;
+} ZsVecCopy;
+int zs_copy_vec_batch(const ZsVecCopy* jobs, int32_t n, void* stream);
 
 /* zs_cast_rows: dst[r][col_off + c] = f(src[r][c]) for c < cols, zeros for cols <= c < fill_cols.
  * f = identity or leaky_relu (model/model.py:446).  src fp32 or T (src_f32), dst T or fp32. */

@@ -225,6 +225,85 @@ def test_wgrad_split2_and_shift(zs, dtype, gemm_variant):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(3, 16, 96, 128), (2, 64, 160, 256), (5, 128, 64, 192)])
+def test_conv_epilogue_wide_split2_vec_prevec(zs, dtype, shape, gemm_variant):
+    """The decoder's first conv of a block at widths that reach the 256x256 kernel's register epilogue (n_pad a multiple of
+    256): per-sample pre_vec, lrelu, packed output, pixel-shuffled second output + speaker embedding."""
+    L, layers = zs
+    B, T, Cin, C = shape
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, T, Cin, generator=g)
+    w = torch.randn(2 * C, Cin, 3, generator=g) / math.sqrt(3 * Cin)
+    b = torch.randn(2 * C, generator=g)
+    emb = torch.randn(6, C, generator=g)
+    pre = torch.randn(6, 2 * C, generator=g)                     # per-sample bias in the PACKED channel order
+    cidx = torch.randint(0, 6, (B,), generator=g)
+    ctx = _ctx(layers, dtype)
+    l = _mk_conv(layers, ctx, w, b, split2=True)
+    A = _to_act(layers, ctx, 'x', x)
+    ya = ctx.act('ya', B, T, 2 * C)
+    s = ctx.act('s', B, 2 * T, C)
+    ya.t.fill_(float('nan')); s.t.fill_(float('nan'))
+    l.fwd(A, out=ya, act=L.ZS_ACT_LRELU, slope=0.01, out2=s, vec2=emb.to(ctx.device), idx=cidx.to(ctx.device),
+          store_mode2=L.ZS_STORE_SPLIT2, pre_vec=pre.to(ctx.device))
+    torch.cuda.synchronize()
+    perm = torch.cat([torch.arange(0, 2 * C, 2), torch.arange(1, 2 * C, 2)])
+    inv = torch.empty_like(perm); inv[perm] = torch.arange(2 * C)
+    pre_ref = pre[:, inv]                                        # reference channel order
+    y = F.leaky_relu(_ref_conv(_round(x, dtype), _round(w, dtype), b, 1, True) + pre_ref[cidx].unsqueeze(1), 0.01)
+    shuf = y.permute(0, 2, 1).contiguous().view(B, C, 2, T).permute(0, 1, 3, 2).contiguous().view(B, C, 2 * T)
+    ref_s = (shuf + emb[cidx].unsqueeze(2)).permute(0, 2, 1)
+    _close('ya (packed order)', ya.valid(), y[:, :, perm], _tol(dtype))
+    _close('shuffle+emb', s.valid(), ref_s, _tol(dtype))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(5, 64, 136, 256), (3, 128, 96, 384), (9, 32, 64, 250), (4, 16, 48, 256)])
+def test_dgrad_epilogue_mask_add_colsum(zs, dtype, shape, gemm_variant):
+    """k = 1 data gradient with everything the decoder's backward hangs on it: lrelu' mask, residual add, per-sample column
+    sums of the raw gradient (nn.Embedding backward) from a column offset, stores limited to out_cols."""
+    L, layers = zs
+    B, T, Cout, Cin = shape
+    g = torch.Generator().manual_seed(41)
+    w = torch.randn(Cout, Cin, generator=g) / math.sqrt(Cout)
+    dy = _round(torch.randn(B, T, Cout, generator=g), dtype)
+    ysrc = _round(torch.randn(B, T, Cin, generator=g), dtype)    # forward activation whose sign gives the lrelu' mask
+    add = _round(torch.randn(B, T, Cin, generator=g), dtype)
+    ctx = _ctx(layers, dtype)
+    l = _mk_conv(layers, ctx, w, None)
+    dY = _to_act(layers, ctx, 'dy', dy)
+    Ys, Ad = _to_act(layers, ctx, 'ys', ysrc), _to_act(layers, ctx, 'ad', add)
+    raw = torch.einsum('btn,nc->btc', dy, _round(w, dtype))
+    mask = torch.where(ysrc > 0, torch.ones(()), torch.full((), 0.01))
+    col0 = (Cin // 2) // 8 * 8
+    for mode in ('mask', 'add', 'plain'):
+        out = ctx.act('o_' + mode, B, T, Cin)
+        out.t.fill_(float('nan'))
+        cs = torch.full((B, Cin), 0.5, device=ctx.device)
+        kw = dict(colsum=(cs.data_ptr(), Cin, col0 if mode == 'plain' else 0))
+        if mode == 'mask':
+            l.dgrad(dY, T, out, dact_src=Ys, slope=0.01, **kw)
+            ref = raw * mask
+        elif mode == 'add':
+            l.dgrad(dY, T, out, add_src=Ad, **kw)
+            ref = raw + add
+        else:
+            l.dgrad(dY, T, out, out_cols=col0, **kw)
+            ref = raw
+        torch.cuda.synchronize()
+        got = out.valid().float().cpu()
+        c0 = col0 if mode == 'plain' else 0
+        if mode == 'plain':
+            _close('dgrad ' + mode, got[:, :, :col0], ref[:, :, :col0], _tol(dtype))
+            assert torch.isnan(got[:, :, col0:]).all(), 'columns past out_cols must not be stored'
+        else:
+            _close('dgrad ' + mode, got, ref, _tol(dtype))
+        want = 0.5 + raw.sum(1)[:, c0:]
+        _close('colsum ' + mode, cs[:, :Cin - c0], want, _tol(dtype))
+        assert (cs[:, Cin - c0:] == 0.5).all()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('res', ['none', 'identity', 'avgpool', 'avgpool_odd', 'upsample'])
 def test_instnorm(zs, dtype, res):
     L, layers = zs

@@ -36,14 +36,101 @@ __global__ void pack_weight_kernel(const ZsPackWeight p) {
   pack_weight_body<T>(p, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
 
+// Tiled variant (taps <= PK_MAX_TAPS): a block moves a tile of R destination rows x I inner positions x all taps through LDS,
+// so that both sides are coalesced -- the source run that is contiguous in memory is (ci, tap) for a fixed output channel, the
+// destination run is the inner index.  transpose 0: rows = n, inner = ci (16 x 128); transpose 1: rows = ci, inner = n (32 x 64).
+// The element-per-thread kernel above reads the transposed layout with a stride of Cin*k floats per lane (1.1 TB/s).
+constexpr int PK_THREADS = 256, PK_MAX_TAPS = 7;      // 57 KiB of LDS at 7 taps (below the 64 KiB a launch gets without an attribute)
+__host__ __device__ inline int pk_rows(int transpose) { return transpose ? 32 : 16; }
+__host__ __device__ inline int pk_inner(int transpose) { return transpose ? 64 : 128; }
+inline int pk_tiles(const ZsPackWeight& p) {
+  return ((p.n_rows + pk_rows(p.transpose) - 1) / pk_rows(p.transpose)) * ((p.inner_pad + pk_inner(p.transpose) - 1) / pk_inner(p.transpose));
+}
+inline size_t pk_lds_bytes(int taps) { return (size_t)16 * (128 * taps + 1) * sizeof(float) > (size_t)64 * (32 * taps + 1) * sizeof(float)
+                                                  ? (size_t)16 * (128 * taps + 1) * sizeof(float) : (size_t)64 * (32 * taps + 1) * sizeof(float); }
+
+template <typename T, int TAPS, int TR>
+__device__ __forceinline__ void pack_tile(const ZsPackWeight& p, int tile, float* lds) {
+  constexpr int R = TR ? 32 : 16, I = TR ? 64 : 128;
+  const int tid = threadIdx.x;
+  const int tiles_i = (p.inner_pad + I - 1) / I;
+  const int tr = tile / tiles_i, ti = tile - tr * tiles_i;
+  const int r0 = tr * R, i0 = ti * I;
+  if (r0 >= p.n_rows) return;
+  const int half = p.Cout >> 1;
+  auto co_of = [&](int n) { return p.row_perm ? p.row_perm[n] : (p.co_split2 ? (n < half ? 2 * n : 2 * (n - half) + 1) : n); };
+  if (TR == 0) {
+    constexpr int RUN = I * TAPS, PITCH = RUN + 1;            // lds[rl][il * TAPS + tap]
+    for (int e = tid; e < R * RUN; e += PK_THREADS) {
+      const int rl = e / RUN, x = e - rl * RUN;
+      const int il = x / TAPS, tap = x - il * TAPS;
+      const int n = r0 + rl, ci = i0 + il;
+      float v = 0.f;
+      if (n < p.Cout && ci < p.Cin) v = p.W[(int64_t)co_of(n) * p.so + (int64_t)ci * p.si + (int64_t)tap * p.sj];
+      lds[rl * PITCH + x] = v;
+    }
+  } else {
+    constexpr int RUN = R * TAPS, PITCH = RUN + 1;            // lds[il][rl * TAPS + tap]
+    for (int e = tid; e < I * RUN; e += PK_THREADS) {
+      const int il = e / RUN, x = e - il * RUN;
+      const int rl = x / TAPS, tap = x - rl * TAPS;
+      const int n = i0 + il, ci = r0 + rl;
+      float v = 0.f;
+      if (n < p.Cout && ci < p.Cin) v = p.W[(int64_t)co_of(n) * p.so + (int64_t)ci * p.si + (int64_t)tap * p.sj];
+      lds[il * PITCH + x] = v;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < R * TAPS * I; e += PK_THREADS) {
+    const int il = e % I, t2 = e / I;
+    const int tap = t2 % TAPS, rl = t2 / TAPS;
+    const int row = r0 + rl, inner = i0 + il;
+    if (row < p.n_rows && inner < p.inner_pad) {
+      const float v = TR ? lds[il * (R * TAPS + 1) + rl * TAPS + tap] : lds[rl * (I * TAPS + 1) + il * TAPS + tap];
+      stT<T>(p.dst, (int64_t)(row + p.row_offset) * p.ldw + p.col_offset + tap * p.inner_pad + inner, v);
+    }
+  }
+  const int tail0 = TAPS * p.inner_pad, tw = p.n_cols - tail0;      // columns past the last tap: zeros
+  if (ti == 0 && tw > 0) {
+    for (int e = tid; e < R * tw; e += PK_THREADS) {
+      const int rl = e / tw, k = e - rl * tw;
+      if (r0 + rl < p.n_rows) stT<T>(p.dst, (int64_t)(r0 + rl + p.row_offset) * p.ldw + p.col_offset + tail0 + k, 0.f);
+    }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void pack_tile_any(const ZsPackWeight& p, int tile, float* lds) {
+#define ZS_PK_CASE(K) case K: if (p.transpose) pack_tile<T, K, 1>(p, tile, lds); else pack_tile<T, K, 0>(p, tile, lds); break;
+  switch (p.taps) { ZS_PK_CASE(1) ZS_PK_CASE(2) ZS_PK_CASE(3) ZS_PK_CASE(4) ZS_PK_CASE(5) ZS_PK_CASE(6) ZS_PK_CASE(7) default: break; }
+#undef ZS_PK_CASE
+}
+
+template <typename T>
+__global__ __launch_bounds__(PK_THREADS) void pack_weight_tiled_kernel(const ZsPackWeight p) {
+  extern __shared__ float pk_lds[];
+  pack_tile_any<T>(p, blockIdx.x, pk_lds);
+}
+
 // up to PACK_BATCH jobs per launch (the per-step repack of a net is ~40 small jobs: one launch instead of 40)
 constexpr int PACK_BATCH = 32;
 struct PackBatch { ZsPackWeight job[PACK_BATCH]; };
 
 template <typename T>
-__global__ void pack_weight_batch_kernel(const PackBatch b) {
+__global__ __launch_bounds__(PK_THREADS) void pack_weight_batch_kernel(const PackBatch b) {
+  extern __shared__ float pk_lds[];
   const ZsPackWeight& p = b.job[blockIdx.y];
-  pack_weight_body<T>(p, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+  if (p.taps <= PK_MAX_TAPS) pack_tile_any<T>(p, blockIdx.x, pk_lds);       // (block-uniform)
+  else pack_weight_body<T>(p, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+}
+
+// ---- small vector copies, one launch for all -------------------------------------------------------
+constexpr int VEC_BATCH = 32;
+struct VecBatch { ZsVecCopy job[VEC_BATCH]; };
+__global__ void copy_vec_batch_kernel(const VecBatch b) {
+  const ZsVecCopy& j = b.job[blockIdx.y];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < j.len; i += gridDim.x * blockDim.x)
+    j.dst[(int64_t)i * j.dst_stride] = j.src[(int64_t)i * j.src_stride];
 }
 
 // ---- cast_rows -------------------------------------------------------------------------------------
@@ -338,7 +425,13 @@ static int pack_check(const ZsPackWeight* p) {
 extern "C" int zs_pack_weight(const ZsPackWeight* p, void* stream) {
   int rc = pack_check(p);
   if (rc) return rc;
-  ZS_DISPATCH(p->dtype, pack_weight_kernel, dim3(nblocks((int64_t)p->n_rows * p->n_cols, 4096)), dim3(NTE), stream, *p);
+  if (p->taps <= PK_MAX_TAPS) {
+    const size_t lds = pk_lds_bytes(p->taps);
+    if (p->dtype == ZS_F32) hipLaunchKernelGGL(pack_weight_tiled_kernel<float>, dim3(pk_tiles(*p)), dim3(PK_THREADS), lds, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL(pack_weight_tiled_kernel<bf16_t>, dim3(pk_tiles(*p)), dim3(PK_THREADS), lds, (hipStream_t)stream, *p);
+  } else {
+    ZS_DISPATCH(p->dtype, pack_weight_kernel, dim3(nblocks((int64_t)p->n_rows * p->n_cols, 4096)), dim3(NTE), stream, *p);
+  }
   return zs_check_launch("zs_pack_weight");
 }
 
@@ -354,13 +447,37 @@ extern "C" int zs_pack_weight_batch(const ZsPackWeight* jobs, int32_t n, void* s
     PackBatch b;
     memset(&b, 0, sizeof(b));
     unsigned gx = 1;
+    int max_taps = 1;
     for (int i = 0; i < m; ++i) {
       b.job[i] = jobs[i0 + i];
-      const unsigned nb = nblocks((int64_t)jobs[i0 + i].n_rows * jobs[i0 + i].n_cols, 4096);
+      const ZsPackWeight& j = jobs[i0 + i];
+      const unsigned nb = j.taps <= PK_MAX_TAPS ? (unsigned)pk_tiles(j) : nblocks((int64_t)j.n_rows * j.n_cols, 4096);
       if (nb > gx) gx = nb;
+      if (j.taps <= PK_MAX_TAPS && j.taps > max_taps) max_taps = j.taps;
     }
-    ZS_DISPATCH(jobs[0].dtype, pack_weight_batch_kernel, dim3(gx, (unsigned)m), dim3(NTE), stream, b);
+    const size_t lds = pk_lds_bytes(max_taps);
+    if (jobs[0].dtype == ZS_F32) hipLaunchKernelGGL(pack_weight_batch_kernel<float>, dim3(gx, (unsigned)m), dim3(PK_THREADS), lds, (hipStream_t)stream, b);
+    else hipLaunchKernelGGL(pack_weight_batch_kernel<bf16_t>, dim3(gx, (unsigned)m), dim3(PK_THREADS), lds, (hipStream_t)stream, b);
     int rc = zs_check_launch("zs_pack_weight_batch");
+    if (rc) return rc;
+  }
+  return ZS_OK;
+}
+
+extern "C" int zs_copy_vec_batch(const ZsVecCopy* jobs, int32_t n, void* stream) {
+  ZS_REQUIRE(jobs && n > 0, "zs_copy_vec_batch: no jobs");
+  for (int i = 0; i < n; ++i)
+    ZS_REQUIRE(jobs[i].src && jobs[i].dst && jobs[i].len > 0, "zs_copy_vec_batch: bad job %d", i);
+  for (int i0 = 0; i0 < n; i0 += VEC_BATCH) {
+    const int m = n - i0 < VEC_BATCH ? n - i0 : VEC_BATCH;
+    VecBatch b;
+    memset(&b, 0, sizeof(b));
+    int mx = 1;
+    for (int i = 0; i < m; ++i) { b.job[i] = jobs[i0 + i]; if (jobs[i0 + i].len > mx) mx = jobs[i0 + i].len; }
+    unsigned gx = (unsigned)((mx + 255) / 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(copy_vec_batch_kernel, dim3(gx, (unsigned)m), dim3(256), 0, (hipStream_t)stream, b);
+    int rc = zs_check_launch("zs_copy_vec_batch");
     if (rc) return rc;
   }
   return ZS_OK;

@@ -99,6 +99,27 @@ __device__ __forceinline__ void store_group(OT* base, int64_t row, int64_t ld, i
 template <typename T, int NTHREADS>
 __device__ __forceinline__ void epilogue_finish(const ZsGemmConv& p, const float* sC, int M, int m0, int n0, int tid, int g);
 
+// per-sample column sums of the staged [NTHREADS/2 rows][128 columns] fp32 tile (ZsGemmConv.colsum; the host admits it only
+// without bias / pre_vec / activation, so the staged accumulators are the values): whole samples per tile, one owner per (b, n)
+template <int NTHREADS>
+__device__ __forceinline__ void epilogue_colsum(const ZsGemmConv& p, const float* sC, int M, int m0, int n0, int tid) {
+  if (p.colsum == nullptr) return;
+  const int ns = (NTHREADS / 2) / p.T_out;
+  for (int w = tid; w < ns * 128; w += NTHREADS) {
+    const int col = w & 127, r0 = (w >> 7) * p.T_out;
+    const int n = n0 + col, m = m0 + r0;
+    if (n >= p.N || n < p.colsum_col0 || m >= M) continue;
+    const float* q = sC + r0 * CPITCH + col;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int r = 0;
+    for (; r + 4 <= p.T_out; r += 4) {
+      a0 += q[(r + 0) * CPITCH]; a1 += q[(r + 1) * CPITCH]; a2 += q[(r + 2) * CPITCH]; a3 += q[(r + 3) * CPITCH];
+    }
+    for (; r < p.T_out; ++r) a0 += q[r * CPITCH];
+    p.colsum[(int64_t)(m / p.T_out) * p.colsum_ld + (n - p.colsum_col0)] += (a0 + a1) + (a2 + a3);
+  }
+}
+
 template <typename T, int NTHREADS>
 __device__ __forceinline__ void gemm_epilogue(const ZsGemmConv& p, f32x16 (&acc)[2][2], float* sC, int M, int m0, int n0,
                                               int wm, int wn, int tid, int g) {
@@ -114,6 +135,7 @@ __device__ __forceinline__ void gemm_epilogue(const ZsGemmConv& p, f32x16 (&acc)
         sC[row * CPITCH + col] = acc[mi][ni][r];
       }
   __syncthreads();
+  epilogue_colsum<NTHREADS>(p, sC, M, m0, n0, tid);
   epilogue_finish<T, NTHREADS>(p, sC, M, m0, n0, tid, g);
 }
 
@@ -962,6 +984,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_conv_p8_kernel(const ZsGemmConv p
       }
     }
     __syncthreads();
+    epilogue_colsum<PNT>(p, sC, M, m0, n0 + h * 128, tid);
     epilogue_finish<T, PNT>(p, sC, M, m0, n0 + h * 128, tid, g);
     __syncthreads();
   }
@@ -1003,6 +1026,216 @@ template <> struct Mma16<float> {
   ZS_M16_MMA(fa11, b1, cq[1][0]); ZS_M16_MMA(fa11, b3, cq[1][1]); ZS_M16_MMA(fa21, b1, cq[2][0]); ZS_M16_MMA(fa21, b3, cq[2][1]); \
   ZS_M16_MMA(fa31, b1, cq[3][0]); ZS_M16_MMA(fa31, b3, cq[3][1]);                \
   __builtin_amdgcn_s_setprio(0);
+
+__device__ __forceinline__ bool al16(const void* q, int64_t pitch_bytes) { return ((((uintptr_t)q) | (uintptr_t)pitch_bytes) & 15) == 0; }
+
+// which problems the register epilogue of the 256x256 kernel takes (wave-uniform: depends on the launch parameters only)
+__device__ __forceinline__ bool p8_regs_epilogue_ok(const ZsGemmConv& p) {
+  const int half = p.N >> 1;
+  const bool split = (p.out && p.store_mode == ZS_STORE_SPLIT2) || (p.out2 && p.store_mode2 == ZS_STORE_SPLIT2);
+  return (p.out == nullptr || (!p.out_f32 && al16(p.out, p.ldc * 2) && ((p.out_gstride * 2) & 15) == 0 && (p.out_cols & 7) == 0)) &&
+         (p.out2 == nullptr || (al16(p.out2, p.ldc2 * 2) && (p.out2_cols & 7) == 0 && p.dact_src == nullptr && p.add_src == nullptr)) &&
+         (p.dact_src == nullptr || al16(p.dact_src, p.dact_ld * 2)) &&
+         (p.add_src == nullptr || (!p.add_f32 && al16(p.add_src, p.add_ld * 2))) &&
+         ((p.pre_vec == nullptr && p.vec2 == nullptr) || (p.T_out & 15) == 0) && (!split || (half & 7) == 0) &&
+         (p.act == ZS_ACT_NONE || p.act == ZS_ACT_LRELU) &&
+         (p.colsum == nullptr || ((PBM % p.T_out) == 0 && p.out2 == nullptr));
+}
+
+// Register epilogue of the 256x256 kernels (bf16 outputs): bias, the per-sample vector and the activation are applied to the
+// accumulators in registers and the WHOLE tile is staged as bf16 (132 KiB), so the finish is a deeply unrolled LDS -> global copy
+// with 16-byte accesses that also applies what needs a second operand (lrelu' mask of dact_src, add_src; all of a thread's loads
+// in flight at once) and the pixel-shuffle row mapping.  out2 (= value + vec2[idx[b]]) is staged and copied the same way from
+// the values still in registers; colsum (per-sample column sums: the nn.Embedding part of the backward) reads the staged tile.
+// HAS2 (out2 given) is a template parameter so that without it the accumulators die at the first staging (registers for the copy).
+template <bool HAS2>
+__device__ __forceinline__ void p8_regs_epilogue(const ZsGemmConv& p, f32x4_m (&c)[2][2][4][2], unsigned char* smem, int M, int m0, int n0,
+                                                 int tid, int lane, int wr, int wc, int g) {
+  constexpr int PT = 264;                                           // bf16 pitch: 528-byte rows
+  unsigned short* sT = reinterpret_cast<unsigned short*>(smem);
+  const int colb = wc * 64 + (lane & 15);
+  const int rbase = wr * 128 + 4 * (lane >> 4);
+  const int half = p.N >> 1;
+  // sample (row of pre_vec / vec2) of each 16-row block of this wave: T_out is a multiple of 16 when they are given
+  int64_t bsel[2][4];
+  const bool need_b = p.pre_vec != nullptr || p.vec2 != nullptr;
+#pragma unroll
+  for (int mq = 0; mq < 2; ++mq)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int mb = m0 + wr * 128 + mq * 64 + mt * 16;
+      bsel[mq][mt] = (need_b && mb < M) ? p.vec_idx[mb / p.T_out] : 0;
+    }
+#pragma unroll
+  for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col = colb + nq * 32 + nt * 16;
+      const int n = n0 + col;
+      const bool cval = n < p.N;
+      const float bv = (p.bias != nullptr && cval) ? p.bias[(int64_t)g * p.bias_gstride + n] : 0.f;
+      float pv[2][4];
+#pragma unroll
+      for (int mq = 0; mq < 2; ++mq)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) pv[mq][mt] = bv;
+      if (p.pre_vec != nullptr && cval) {
+#pragma unroll
+        for (int mq = 0; mq < 2; ++mq)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) pv[mq][mt] += p.pre_vec[bsel[mq][mt] * p.pre_vec_ld + n];
+      }
+#pragma unroll
+      for (int mq = 0; mq < 2; ++mq)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int i4 = 0; i4 < 4; ++i4) {
+            float v = c[mq][nq][mt][nt][i4] + pv[mq][mt];
+            if (p.act == ZS_ACT_LRELU) v = lrelu_f(v, p.slope);
+            if (!cval) v = 0.f;                                     // columns [N, out_cols) are written as zeros
+            if constexpr (HAS2) c[mq][nq][mt][nt][i4] = v;
+            sT[(rbase + mq * 64 + mt * 16 + i4) * PT + col] = f2bf(v);
+          }
+    }
+  __syncthreads();
+
+  if (!HAS2 && p.colsum != nullptr) {
+    // per-sample column sums of the staged values (before mask / add): one thread per (column, half of the tile's samples);
+    // a tile holds whole samples (256 % T_out == 0), so every (sample, column) has one owner: plain += , no atomics
+    const int ns = PBM / p.T_out;
+    const int col = tid & 255, n = n0 + col, hs = tid >> 8;
+    const int s0 = ns >= 2 ? hs * (ns >> 1) : 0, s1 = ns >= 2 ? s0 + (ns >> 1) : (hs == 0 ? 1 : 0);
+    if (n < p.N && n >= p.colsum_col0) {
+      for (int s = s0; s < s1; ++s) {
+        const int r0 = s * p.T_out, m = m0 + r0;
+        if (m >= M) break;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const unsigned short* q = sT + r0 * PT + col;
+        int r = 0;
+        for (; r + 4 <= p.T_out; r += 4) {
+          a0 += bf2f(q[(r + 0) * PT]); a1 += bf2f(q[(r + 1) * PT]); a2 += bf2f(q[(r + 2) * PT]); a3 += bf2f(q[(r + 3) * PT]);
+        }
+        for (; r < p.T_out; ++r) a0 += bf2f(q[r * PT]);
+        float* d = p.colsum + (int64_t)(m / p.T_out) * p.colsum_ld + (n - p.colsum_col0);
+        *d += (a0 + a1) + (a2 + a3);
+      }
+    }
+  }
+
+  const int c8 = (tid & 31) * 8, r0 = tid >> 5;                     // 32 x 16-byte groups per row, 16 rows per pass
+  const int n = n0 + c8;
+  if (p.out != nullptr) {
+    unsigned short* outp = (unsigned short*)p.out + (int64_t)g * p.out_gstride;
+    const bool sp = p.store_mode == ZS_STORE_SPLIT2;
+    const int hi = sp ? (n >= half) : 0;
+    const int oc = n - hi * half;
+    const bool cok = sp ? (n < p.N) : (n < p.out_cols);
+    const bool second = p.dact_src != nullptr || p.add_src != nullptr;
+    if (cok && !second) {
+#pragma unroll 8
+      for (int it = 0; it < 16; ++it) {
+        const int row = r0 + 16 * it;
+        const int m = m0 + row;
+        if (m < M) {
+          const uint4 w = *reinterpret_cast<const uint4*>(sT + row * PT + c8);
+          const int64_t orow = sp ? 2 * (int64_t)m + hi : (int64_t)m;
+          *reinterpret_cast<uint4*>(outp + orow * p.ldc + oc) = w;
+        }
+      }
+    } else if (!HAS2 && cok) {                                      // (out2 excludes dact_src / add_src: p8_regs_epilogue_ok)
+      const bf16_t* dsrc = (const bf16_t*)p.dact_src;
+      const bf16_t* asrc = (const bf16_t*)p.add_src;
+      const bool tail = n + 8 > p.N;                               // the group reaches into the zero columns [N, out_cols)
+#pragma unroll 1
+      for (int it0 = 0; it0 < 16; it0 += 8) {
+        Raw8<bf16_t> rd[8], ra[8];
+        uint4 w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int row = r0 + 16 * (it0 + u);
+          const int m = min(m0 + row, M - 1);
+          if (dsrc) rd[u].ld(dsrc + (int64_t)m * p.dact_ld + n);
+          if (asrc) ra[u].ld(asrc + (int64_t)m * p.add_ld + n);
+          w[u] = *reinterpret_cast<const uint4*>(sT + row * PT + c8);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int row = r0 + 16 * (it0 + u);
+          const int m = m0 + row;
+          if (m < M) {
+            float v[8], y[8];
+            Raw8<bf16_t> rw; rw.a = w[u]; rw.cvt(v);
+            if (dsrc) {
+              rd[u].cvt(y);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] *= dlrelu_f(y[j], p.slope);
+            }
+            if (asrc) {
+              ra[u].cvt(y);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] += y[j];
+            }
+            if (tail) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) if (n + j >= p.N) v[j] = 0.f;
+            }
+            const int64_t orow = sp ? 2 * (int64_t)m + hi : (int64_t)m;
+            store8<bf16_t>(outp + orow * p.ldc + oc, v);
+          }
+        }
+      }
+    }
+  }
+  if constexpr (HAS2) {
+    __syncthreads();                                                // every thread is done with the first staging
+    const bool sp = p.store_mode2 == ZS_STORE_SPLIT2;
+#pragma unroll
+    for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int col = colb + nq * 32 + nt * 16;
+        const int nn = n0 + col;
+        const bool cval = nn < p.N;
+        const int ocv = sp ? (nn >= half ? nn - half : nn) : nn;
+        float ev[2][4];
+#pragma unroll
+        for (int mq = 0; mq < 2; ++mq)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) ev[mq][mt] = 0.f;
+        if (p.vec2 != nullptr && cval) {
+#pragma unroll
+          for (int mq = 0; mq < 2; ++mq)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) ev[mq][mt] = p.vec2[bsel[mq][mt] * p.vec2_ld + ocv];
+        }
+#pragma unroll
+        for (int mq = 0; mq < 2; ++mq)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4)
+              sT[(rbase + mq * 64 + mt * 16 + i4) * PT + col] = f2bf(c[mq][nq][mt][nt][i4] + ev[mq][mt]);
+      }
+    __syncthreads();
+    unsigned short* outp = (unsigned short*)p.out2;
+    const int hi = sp ? (n >= half) : 0;
+    const int oc = n - hi * half;
+    const bool cok = sp ? (n < p.N) : (n < p.out2_cols);
+    if (cok) {
+#pragma unroll 8
+      for (int it = 0; it < 16; ++it) {
+        const int row = r0 + 16 * it;
+        const int m = m0 + row;
+        if (m < M) {
+          const uint4 w = *reinterpret_cast<const uint4*>(sT + row * PT + c8);
+          const int64_t orow = sp ? 2 * (int64_t)m + hi : (int64_t)m;
+          *reinterpret_cast<uint4*>(outp + orow * p.ldc2 + oc) = w;
+        }
+      }
+    }
+  }
+}
 
 template <typename T>
 __global__ __launch_bounds__(PNT, 2) void gemm_conv_p8m16_kernel(const ZsGemmConv p) {
@@ -1165,53 +1398,12 @@ __global__ __launch_bounds__(PNT, 2) void gemm_conv_p8m16_kernel(const ZsGemmCon
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // Fast epilogue for the common case (bf16 rows out, only bias + activation): every wave applies bias/activation to its
-  // accumulators in registers and stages the WHOLE 256x256 tile as bf16 (132 KiB), so all accumulators are dead at once and
-  // the finish is a pure, deeply unrolled LDS -> global copy with 16-byte accesses (the two-half fp32 path below keeps half
-  // of the accumulators live during its finish and is limited to two rows in flight per thread).
+  // register epilogue (bf16 outputs; see p8_regs_epilogue): the two-half fp32 path below keeps two rows in flight per thread and
+  // costs as much as the whole K loop of a 1024-deep layer -- it is left for fp32 outputs and odd alignments
   if constexpr (sizeof(T) == 2) {
-    const bool fast = p.out != nullptr && !p.out_f32 && p.pre_vec == nullptr && p.dact_src == nullptr && p.add_src == nullptr &&
-                      p.out2 == nullptr && p.store_mode == ZS_STORE_ROWS && (p.act == ZS_ACT_NONE || p.act == ZS_ACT_LRELU) &&
-                      ((((uintptr_t)p.out) | (uintptr_t)(p.ldc * 2) | (uintptr_t)(p.out_gstride * 2)) & 15) == 0 && (p.out_cols & 7) == 0;
-    if (fast) {
-      constexpr int PT = 264;                                       // bf16 pitch: 528-byte rows
-      unsigned short* sT = reinterpret_cast<unsigned short*>(smem);
-      const int colb = wc * 64 + (lane & 15);
-      const int rbase = wr * 128 + 4 * (lane >> 4);
-#pragma unroll
-      for (int nq = 0; nq < 2; ++nq)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          const int col = colb + nq * 32 + nt * 16;
-          const bool cval = n0 + col < p.N;
-          const float bv = (p.bias != nullptr && cval) ? p.bias[(int64_t)g * p.bias_gstride + n0 + col] : 0.f;
-#pragma unroll
-          for (int mq = 0; mq < 2; ++mq)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-              for (int i4 = 0; i4 < 4; ++i4) {
-                float v = c[mq][nq][mt][nt][i4] + bv;
-                if (p.act == ZS_ACT_LRELU) v = lrelu_f(v, p.slope);
-                if (!cval) v = 0.f;                                 // columns [N, out_cols) are written as zeros
-                sT[(rbase + mq * 64 + mt * 16 + i4) * PT + col] = f2bf(v);
-              }
-        }
-      __syncthreads();
-      unsigned short* outp = (unsigned short*)p.out + (int64_t)g * p.out_gstride;
-      const int c8 = (tid & 31) * 8, r0 = tid >> 5;                 // 32 x 16-byte groups per row, 16 rows per pass
-      const int n = n0 + c8;
-      if (n < p.out_cols) {
-#pragma unroll 8
-        for (int it = 0; it < 16; ++it) {
-          const int row = r0 + 16 * it;
-          const int m = m0 + row;
-          if (m < M) {
-            const uint4 w = *reinterpret_cast<const uint4*>(sT + row * PT + c8);
-            *reinterpret_cast<uint4*>(outp + (int64_t)m * p.ldc + n) = w;
-          }
-        }
-      }
+    if (p8_regs_epilogue_ok(p)) {
+      if (p.out2 != nullptr) p8_regs_epilogue<true>(p, c, smem, M, m0, n0, tid, lane, wr, wc, g);
+      else p8_regs_epilogue<false>(p, c, smem, M, m0, n0, tid, lane, wr, wc, g);
       return;
     }
   }
@@ -1235,6 +1427,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_conv_p8m16_kernel(const ZsGemmCon
                 sC[(rbase + mq * 64 + mt * 16 + i) * CPITCH + cb + nq * 32 + nt * 16] = c[mq][nq][mt][nt][i];
     }
     __syncthreads();
+    epilogue_colsum<PNT>(p, sC, M, m0, n0 + h * 128, tid);
     epilogue_finish<T, PNT>(p, sC, M, m0, n0 + h * 128, tid, g);
     __syncthreads();
   }
@@ -1882,6 +2075,9 @@ extern "C" int zs_gemm_conv(const ZsGemmConv* p, void* stream) {
   if (p->store_mode == ZS_STORE_SPLIT2 || (p->out2 && p->store_mode2 == ZS_STORE_SPLIT2))
     ZS_REQUIRE(p->N % 2 == 0, "zs_gemm_conv: SPLIT2 needs even N");
   ZS_REQUIRE(!(p->pre_vec || p->vec2) || p->vec_idx, "zs_gemm_conv: vec_idx missing");
+  ZS_REQUIRE(!p->colsum || (128 % p->T_out == 0 && p->colsum_col0 >= 0 && p->colsum_col0 < p->N && !p->bias && !p->pre_vec &&
+                            p->act == ZS_ACT_NONE && p->groups <= 1),
+             "zs_gemm_conv: colsum needs T_out (%d) to divide 128, 0 <= colsum_col0 < N and no bias / pre_vec / activation / groups", p->T_out);
   const int groups = p->groups > 0 ? p->groups : 1;
   const int64_t M = (int64_t)p->B * p->T_out;
   const int64_t tiles = ((M + BM - 1) / BM) * ((p->N + BN - 1) / BN);

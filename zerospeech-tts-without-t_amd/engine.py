@@ -8,7 +8,7 @@ import os
 import torch
 
 from . import _lib as L
-from .layers import Act, ConvLayer, GruLayer, fork_side, join_side, rup
+from .layers import Act, ConvLayer, GruLayer, colsum_ok, fork_side, join_side, rup
 
 LRELU = L.ZS_ACT_LRELU
 EPS_IN = 1e-5
@@ -397,10 +397,17 @@ class DecoderEngine(_Taped):
         self.linear.dgrad(dlogit, T, dz5, dact_src=h5, slope=ns)
         self.dense5.wgrad(dz5, cat3)
         dcat3 = c.act('d_dcat3' + tag, B, T, (2 if self.fold5 else 3) * ch)
-        self.dense5.dgrad(dz5, T, dcat3)
-        if not self.fold5:
-            self._combine(dcat3.sub(2 * ch, ch), T, 0, 0, None, emb_i=4)                   # d emb5 via append_emb
+        # the embedding parts of the k = 1 data gradients (per-sample column sums) come out of the GEMM epilogues when whole
+        # samples fit a tile (ZsGemmConv.colsum); otherwise a zs_grad_combine pass over the gradient computes them
+        fuse = colsum_ok(T) and os.environ.get('ZS_FUSE_COLSUM', '1') == '1'
+        slot = lambda k, col0=0: (L.ptr(self._embsum, k * B * ch), ch, col0)
+        if not self.fold5 and fuse:                                                          # d emb5 via append_emb: the third
+            self.dense5.dgrad(dz5, T, dcat3, colsum=slot(4, 2 * ch), out_cols=2 * ch)        # column block is summed, not stored
         else:
+            self.dense5.dgrad(dz5, T, dcat3)
+            if not self.fold5:
+                self._combine(dcat3.sub(2 * ch, ch), T, 0, 0, None, emb_i=4)
+        if self.fold5:
             # the folded emb5 block: with s[b] = sum_t dz5[b, t, :]  (per-sample column sums, slot 5)
             #   d emb5 (per sample, slot 4) += s[b] . W5[:, 2ch:]          d W5[:, 2ch:] (+)= sum_b s[b]^T emb5[c_b]
             self._combine(Act(dz5.t, B, T, ch, dz5.ld), T, 0, 0, None, emb_i=5)
@@ -419,22 +426,32 @@ class DecoderEngine(_Taped):
         gp = c.act('d_gpA' + tag, B, T + 2, ch)
         gpv = Act(gp.t, B, T, ch, gp.ld)
         post = c.hooks['dec_gru_bwd']() if c.hooks.get('dec_gru_bwd') else None
-        self.gru.bwd(dcat3, ch, cat3, ch, tp['gates'], tp['gru_in'], dgi, dgh, gpv, post_persist=post)
         dx = c.act('d_dxA' + tag, B, T, ch)
-        self._combine(gpv, T, 0, 0, dx, emb_i=4, res_mode=L.ZS_RES_IDENTITY, res=dcat3.sub(0, ch))   # out+emb5 (:353)
+        if fuse:                                                                                     # out+emb5 (:353)
+            self.gru.bwd(dcat3, ch, cat3, ch, tp['gates'], tp['gru_in'], dgi, dgh, dx, add_src=dcat3.sub(0, ch), post_persist=post,
+                         colsum=slot(4))
+        else:
+            self.gru.bwd(dcat3, ch, cat3, ch, tp['gates'], tp['gru_in'], dgi, dgh, gpv, post_persist=post)
+            self._combine(gpv, T, 0, 0, dx, emb_i=4, res_mode=L.ZS_RES_IDENTITY, res=dcat3.sub(0, ch))
         for j in (1, 0):
             la, lb = self.dense[j]
             xin, xe, y1, y1e, y2, stt = tp['dense'][j]
             dz2 = c.act('d_dz2%d' % j + tag, B, T, ch)           # unique per block: read later by the side-stream wgrad
             self._in_bwd(dx, y2, stt, dz2)
             lb.wgrad(dz2, y1e)
-            lb.dgrad(dz2, T, gpv)
             dz1 = c.act('d_dz1%d' % j + tag, B, T, ch)
-            self._combine(gpv, T, 0, 0, dz1, emb_i=3, dact=y1)
+            if fuse:
+                lb.dgrad(dz2, T, dz1, dact_src=y1, slope=ns, colsum=slot(3))
+            else:
+                lb.dgrad(dz2, T, gpv)
+                self._combine(gpv, T, 0, 0, dz1, emb_i=3, dact=y1)
             la.wgrad(dz1, xe)
-            la.dgrad(dz1, T, gpv)
             dn = c.act('d_dxD%d' % j + tag, B, T, ch)
-            self._combine(gpv, T, 0, 0, dn, emb_i=3, res_mode=L.ZS_RES_IDENTITY, res=dx)
+            if fuse:
+                la.dgrad(dz1, T, dn, add_src=dx, colsum=slot(3))
+            else:
+                la.dgrad(dz1, T, gpv)
+                self._combine(gpv, T, 0, 0, dn, emb_i=3, res_mode=L.ZS_RES_IDENTITY, res=dx)
             dx = dn
         for i in (2, 1, 0):
             la, lb = self.convs[i]

@@ -8,6 +8,11 @@ import torch
 from . import _lib as L
 
 
+def colsum_ok(T):
+    """zs_gemm_conv can add the per-sample column sums of its output (ZsGemmConv.colsum) when whole samples fit its tiles."""
+    return T > 0 and 128 % T == 0
+
+
 def rup(x, m):
     return (x + m - 1) // m * m
 
@@ -249,8 +254,8 @@ class ConvLayer(object):
                ldw=self.ldw_d, n_rows=self.n_pad_d, n_cols=self.ldw_d, **common)
         if self.bias_p is not None:
             h = self.Cout // 2
-            self.bias_p[:h].copy_(self.b[0::2])
-            self.bias_p[h:].copy_(self.b[1::2])
+            L.vec_copy(self.bias_p[:h], self.b, c.stream, src_stride=2)
+            L.vec_copy(self.bias_p[h:], self.b[1:], c.stream, src_stride=2)
 
     def bias_ptr(self):
         if self.b is None:
@@ -282,20 +287,23 @@ class ConvLayer(object):
         L.call('zs_gemm_conv', 'ZsGemmConv', c.stream, **kw)
         return T_out
 
-    def dgrad(self, dY, T_x, out, dact_src=None, slope=0.0, add_src=None, out_f32=False, add_f32=False):
+    def dgrad(self, dY, T_x, out, dact_src=None, slope=0.0, add_src=None, out_f32=False, add_f32=False, colsum=None, out_cols=None):
         """dY: Act [B,T_y,Cout] (ld >= cout_pad).  out: Act with B*(T_x+pad_l+pad_r) rows (padded domain; equals the
-        input gradient when k == 1).  Optional epilogue: *lrelu'(dact_src), +add_src (both only meaningful for k == 1)."""
+        input gradient when k == 1).  Optional epilogue: *lrelu'(dact_src), +add_src (both only meaningful for k == 1).
+        colsum = (fp32 pointer, ld, col0): per-sample column sums of the raw gradient, columns >= col0 (see colsum_ok)."""
         c = self.ctx
         Tp = T_x + self.pad_l + self.pad_r
         kw = dict(dtype=c.dt, A=dY.ptr(), lda=dY.ld, a_batch_stride=dY.T * dY.ld, B=dY.B, T_in=dY.T, T_out=Tp, taps=self.k,
                   stride=self.stride, pad_left=0, pad_mode=L.ZS_PAD_ZERO, gather=1, cin_pad=self.cout_pad,
                   W=L.ptr(self.wd), ldw=self.ldw_d, N=self.Cin, n_pad=self.n_pad_d, act=L.ZS_ACT_NONE, slope=slope,
-                  out=out.ptr(), ldc=out.ld, out_cols=min(out.cols, rup(self.Cin, 32)), store_mode=L.ZS_STORE_ROWS, groups=1,
-                  out_f32=int(out_f32))
+                  out=out.ptr(), ldc=out.ld, out_cols=(out_cols if out_cols is not None else min(out.cols, rup(self.Cin, 32))),
+                  store_mode=L.ZS_STORE_ROWS, groups=1, out_f32=int(out_f32))
         if dact_src is not None:
             kw.update(dact_src=dact_src.ptr(), dact_ld=dact_src.ld)
         if add_src is not None:
             kw.update(add_src=add_src.ptr(), add_ld=add_src.ld, add_f32=int(add_f32))
+        if colsum is not None:
+            kw.update(colsum=colsum[0], colsum_ld=colsum[1], colsum_col0=colsum[2])
         L.call('zs_gemm_conv', 'ZsGemmConv', c.stream, **kw)
         return Tp
 
@@ -420,8 +428,8 @@ class GruLayer(object):
             L.call('zs_pack_weight', 'ZsPackWeight', c.stream, transpose=1, inner_pad=rup(3 * H, c.kc),
                    dst=L.ptr(self.whh_t, d * self.hh_npad_t * self.hh_ldw_t), ldw=self.hh_ldw_t, n_rows=self.hh_npad_t,
                    n_cols=self.hh_ldw_t, **com)
-            self.bih[3 * H * d:3 * H * (d + 1)].copy_(self.b_ih[d])
-            self.bhh[3 * H * d:3 * H * (d + 1)].copy_(self.b_hh[d])
+            L.vec_copy(self.bih[3 * H * d:3 * H * (d + 1)], self.b_ih[d], c.stream)
+            L.vec_copy(self.bhh[3 * H * d:3 * H * (d + 1)], self.b_hh[d], c.stream)
 
     def _work(self, B):
         n = L.lib().zs_gru_work_bytes(B, self.H)
@@ -446,7 +454,7 @@ class GruLayer(object):
         """Test hook: raise if the last persistent pass over this layer's work buffer timed out (synchronises)."""
         L.check(L.lib().zs_gru_check(L.ptr(self._work(B)), B, self.H, self.ctx.stream), 'zs_gru_check')
 
-    def bwd(self, dout, dout_col, out, out_col, gates, X, dgi, dgh, dX, add_src=None, post_persist=None):
+    def bwd(self, dout, dout_col, out, out_col, gates, X, dgi, dgh, dX, add_src=None, post_persist=None, colsum=None):
         """BPTT + parameter gradients + input gradient dX (= dgi W_ih, + add_src).  post_persist: called right after the BPTT
         launch (a capture-time hook: work that should run beside the persistent kernel)."""
         c, H = self.ctx, self.H
@@ -476,4 +484,6 @@ class GruLayer(object):
                   out_cols=min(dX.cols, rup(self.Cin, 32)), groups=1)
         if add_src is not None:
             kw.update(add_src=add_src.ptr(), add_ld=add_src.ld, add_f32=0)
+        if colsum is not None:
+            kw.update(colsum=colsum[0], colsum_ld=colsum[1], colsum_col0=colsum[2])
         L.call('zs_gemm_conv', 'ZsGemmConv', c.stream, **kw)
