@@ -143,8 +143,10 @@ typedef struct {
   const int32_t* row_perm;         /* optional: output row n reads parameter row row_perm[n] (overrides co_split2) */
 } ZsPackWeight;
 int zs_pack_weight(const ZsPackWeight* p, void* stream);
-/* the same for n jobs (one dtype) in ceil(n/32) launches: the per-step repack of a whole net after the optimiser step */
-int zs_pack_weight_batch(const ZsPackWeight* jobs, int32_t n, void* stream);
+/* the same for n jobs (one dtype) in ceil(n/32) launches: the per-step repack of a whole net after the optimiser step.
+ * max_blocks > 0 caps the grid (the workgroups then walk the tile list): a re-pack that runs on a side stream beside a chain of
+ * small kernels must leave them wave slots (about two workgroups per CU still stream at the HBM rate); 0 = one workgroup per tile */
+int zs_pack_weight_batch(const ZsPackWeight* jobs, int32_t n, int32_t max_blocks, void* stream);
 
 /* zs_copy_vec_batch: n small fp32 vector copies in ONE launch, dst[i*dst_stride] = src[i*src_stride] for i < len: the bias
  * re-ordering that goes with the pixel-shuffle packing (co_split2) and the stacked nn.GRU biases, issued with the re-pack. */
@@ -162,6 +164,9 @@ typedef struct {
   void* dst; int64_t ld_dst; int32_t dst_f32; int32_t col_off;
   int64_t rows; int32_t cols, fill_cols;
   int32_t act; float slope;
+  /* optional second destination from the same read (type T): dst2[r][col_off2 + c] = f2(src[r][c]), zeros up to fill_cols2
+   * (the encoder's input goes to the conv bank raw and to the concatenation through leaky_relu, model/model.py:441-446) */
+  void* dst2; int64_t ld_dst2; int32_t col_off2, fill_cols2; int32_t act2; float slope2;
 } ZsCastRows;
 int zs_cast_rows(const ZsCastRows* p, void* stream);
 
@@ -341,6 +346,7 @@ typedef struct {
   const float* sumsq; float max_norm; int32_t write_clipped_grad;
   const int32_t* step_ptr;       /* optional device step count t: bc1 = 1-beta1^t, bc2 = 1-beta2^t computed on device */
   float grad_scale;
+  int32_t max_blocks;            /* > 0: grid cap (see zs_pack_weight_batch); 0 = default */
 } ZsAdam;
 int zs_adam_clip(const ZsAdam* p, void* stream);
 

@@ -38,20 +38,22 @@ __global__ void pack_weight_kernel(const ZsPackWeight p) {
 
 // Tiled variant (taps <= PK_MAX_TAPS): a block moves a tile of R destination rows x I inner positions x all taps through LDS,
 // so that both sides are coalesced -- the source run that is contiguous in memory is (ci, tap) for a fixed output channel, the
-// destination run is the inner index.  transpose 0: rows = n, inner = ci (16 x 128); transpose 1: rows = ci, inner = n (32 x 64).
+// destination run is the inner index.  transpose 0: rows = n, inner = ci (R x 128); transpose 1: rows = ci, inner = n (R x 64);
+// R is the power of two that keeps the tile within 16 KiB of LDS (8 blocks per CU: the kernel is latency-bound otherwise).
 // The element-per-thread kernel above reads the transposed layout with a stride of Cin*k floats per lane (1.1 TB/s).
-constexpr int PK_THREADS = 256, PK_MAX_TAPS = 7;      // 57 KiB of LDS at 7 taps (below the 64 KiB a launch gets without an attribute)
-__host__ __device__ inline int pk_rows(int transpose) { return transpose ? 32 : 16; }
-__host__ __device__ inline int pk_inner(int transpose) { return transpose ? 64 : 128; }
+constexpr int PK_THREADS = 256, PK_MAX_TAPS = 7;
+__host__ __device__ constexpr int pk_pow2_le(int x) { return x >= 64 ? 64 : x >= 32 ? 32 : x >= 16 ? 16 : x >= 8 ? 8 : x >= 4 ? 4 : x >= 2 ? 2 : 1; }
+__host__ __device__ constexpr int pk_inner(int transpose) { return transpose ? 64 : 128; }
+__host__ __device__ constexpr int pk_rows(int transpose, int taps) { return pk_pow2_le((transpose ? 64 : 32) / taps); }
 inline int pk_tiles(const ZsPackWeight& p) {
-  return ((p.n_rows + pk_rows(p.transpose) - 1) / pk_rows(p.transpose)) * ((p.inner_pad + pk_inner(p.transpose) - 1) / pk_inner(p.transpose));
+  const int R = pk_rows(p.transpose, p.taps), I = pk_inner(p.transpose);
+  return ((p.n_rows + R - 1) / R) * ((p.inner_pad + I - 1) / I);
 }
-inline size_t pk_lds_bytes(int taps) { return (size_t)16 * (128 * taps + 1) * sizeof(float) > (size_t)64 * (32 * taps + 1) * sizeof(float)
-                                                  ? (size_t)16 * (128 * taps + 1) * sizeof(float) : (size_t)64 * (32 * taps + 1) * sizeof(float); }
+constexpr size_t PK_LDS_BYTES = (4096 + 128) * sizeof(float);
 
 template <typename T, int TAPS, int TR>
 __device__ __forceinline__ void pack_tile(const ZsPackWeight& p, int tile, float* lds) {
-  constexpr int R = TR ? 32 : 16, I = TR ? 64 : 128;
+  constexpr int R = pk_rows(TR, TAPS), I = pk_inner(TR);
   const int tid = threadIdx.x;
   const int tiles_i = (p.inner_pad + I - 1) / I;
   const int tr = tile / tiles_i, ti = tile - tr * tiles_i;
@@ -61,6 +63,7 @@ __device__ __forceinline__ void pack_tile(const ZsPackWeight& p, int tile, float
   auto co_of = [&](int n) { return p.row_perm ? p.row_perm[n] : (p.co_split2 ? (n < half ? 2 * n : 2 * (n - half) + 1) : n); };
   if (TR == 0) {
     constexpr int RUN = I * TAPS, PITCH = RUN + 1;            // lds[rl][il * TAPS + tap]
+#pragma unroll 4
     for (int e = tid; e < R * RUN; e += PK_THREADS) {
       const int rl = e / RUN, x = e - rl * RUN;
       const int il = x / TAPS, tap = x - il * TAPS;
@@ -71,6 +74,7 @@ __device__ __forceinline__ void pack_tile(const ZsPackWeight& p, int tile, float
     }
   } else {
     constexpr int RUN = R * TAPS, PITCH = RUN + 1;            // lds[il][rl * TAPS + tap]
+#pragma unroll 4
     for (int e = tid; e < I * RUN; e += PK_THREADS) {
       const int il = e / RUN, x = e - il * RUN;
       const int rl = x / TAPS, tap = x - rl * TAPS;
@@ -81,6 +85,7 @@ __device__ __forceinline__ void pack_tile(const ZsPackWeight& p, int tile, float
     }
   }
   __syncthreads();
+#pragma unroll 4
   for (int e = tid; e < R * TAPS * I; e += PK_THREADS) {
     const int il = e % I, t2 = e / I;
     const int tap = t2 % TAPS, rl = t2 / TAPS;
@@ -114,14 +119,22 @@ __global__ __launch_bounds__(PK_THREADS) void pack_weight_tiled_kernel(const ZsP
 
 // up to PACK_BATCH jobs per launch (the per-step repack of a net is ~40 small jobs: one launch instead of 40)
 constexpr int PACK_BATCH = 32;
-struct PackBatch { ZsPackWeight job[PACK_BATCH]; };
+struct PackBatch { ZsPackWeight job[PACK_BATCH]; int32_t tile_start[PACK_BATCH + 1]; int32_t n; };
 
+// one flat tile list over the jobs (tile_start = prefix sums); the workgroups walk it with the grid as stride
 template <typename T>
 __global__ __launch_bounds__(PK_THREADS) void pack_weight_batch_kernel(const PackBatch b) {
   extern __shared__ float pk_lds[];
-  const ZsPackWeight& p = b.job[blockIdx.y];
-  if (p.taps <= PK_MAX_TAPS) pack_tile_any<T>(p, blockIdx.x, pk_lds);       // (block-uniform)
-  else pack_weight_body<T>(p, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+  const int total = b.tile_start[b.n];
+  for (int g = blockIdx.x; g < total; g += gridDim.x) {
+    int j = 0;
+    while (g >= b.tile_start[j + 1]) ++j;                                  // (block-uniform)
+    const ZsPackWeight& p = b.job[j];
+    const int tile = g - b.tile_start[j], ntile = b.tile_start[j + 1] - b.tile_start[j];
+    if (p.taps <= PK_MAX_TAPS) pack_tile_any<T>(p, tile, pk_lds);
+    else pack_weight_body<T>(p, (int64_t)tile * blockDim.x + threadIdx.x, (int64_t)ntile * blockDim.x);
+    __syncthreads();
+  }
 }
 
 // ---- small vector copies, one launch for all -------------------------------------------------------
@@ -136,16 +149,18 @@ __global__ void copy_vec_batch_kernel(const VecBatch b) {
 // ---- cast_rows -------------------------------------------------------------------------------------
 template <typename T>
 __global__ void cast_rows_kernel(const ZsCastRows p) {
-  const int64_t total = p.rows * p.fill_cols;
+  const int fc = (p.dst2 && p.fill_cols2 > p.fill_cols) ? p.fill_cols2 : p.fill_cols;
+  const int64_t total = p.rows * fc;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / p.fill_cols;
-    const int c = (int)(i - r * p.fill_cols);
-    float v = 0.f;
-    if (c < p.cols) {
-      v = p.src_f32 ? ((const float*)p.src)[r * p.ld_src + c] : ldT<T>(p.src, r * p.ld_src + c);
-      if (p.act == ZS_ACT_LRELU) v = lrelu_f(v, p.slope);
+    const int64_t r = i / fc;
+    const int c = (int)(i - r * fc);
+    float x = 0.f;
+    if (c < p.cols) x = p.src_f32 ? ((const float*)p.src)[r * p.ld_src + c] : ldT<T>(p.src, r * p.ld_src + c);
+    if (c < p.fill_cols) {
+      const float v = (p.act == ZS_ACT_LRELU) ? lrelu_f(x, p.slope) : x;
+      if (p.dst_f32) ((float*)p.dst)[r * p.ld_dst + p.col_off + c] = v; else stT<T>(p.dst, r * p.ld_dst + p.col_off + c, v);
     }
-    if (p.dst_f32) ((float*)p.dst)[r * p.ld_dst + p.col_off + c] = v; else stT<T>(p.dst, r * p.ld_dst + p.col_off + c, v);
+    if (p.dst2 && c < p.fill_cols2) stT<T>(p.dst2, r * p.ld_dst2 + p.col_off2 + c, (p.act2 == ZS_ACT_LRELU) ? lrelu_f(x, p.slope2) : x);
   }
 }
 
@@ -332,14 +347,27 @@ __global__ void adam_kernel(const ZsAdam p) {
   }
   const float step_size = p.lr / bc1;
   const float bc2_sqrt = sqrtf(bc2);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float g = p.g[i] * coef;
-    float m = p.m[i], v = p.v[i];
+  auto upd = [&](float& w, float& g, float& m, float& v) {
+    g *= coef;
     m = m + (g - m) * (1.f - p.beta1);                           // exp_avg.lerp_(grad, 1 - beta1)
     v = v * p.beta2 + g * g * (1.f - p.beta2);                   // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
     const float denom = sqrtf(v) / bc2_sqrt + p.eps;
-    p.p[i] = p.p[i] - step_size * (m / denom);
-    p.m[i] = m; p.v[i] = v;
+    w = w - step_size * (m / denom);
+  };
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+  const bool vec = ((((uintptr_t)p.p) | ((uintptr_t)p.g) | ((uintptr_t)p.m) | ((uintptr_t)p.v)) & 15) == 0;
+  const int64_t n4 = vec ? p.n / 4 : 0;
+  for (int64_t i = tid; i < n4; i += nthr) {                     // 16-byte accesses: four streams of 64 B per lane in flight
+    float4 w = reinterpret_cast<float4*>(p.p)[i], g = reinterpret_cast<float4*>(p.g)[i];
+    float4 m = reinterpret_cast<float4*>(p.m)[i], v = reinterpret_cast<float4*>(p.v)[i];
+    upd(w.x, g.x, m.x, v.x); upd(w.y, g.y, m.y, v.y); upd(w.z, g.z, m.z, v.z); upd(w.w, g.w, m.w, v.w);
+    reinterpret_cast<float4*>(p.p)[i] = w; reinterpret_cast<float4*>(p.m)[i] = m; reinterpret_cast<float4*>(p.v)[i] = v;
+    if (p.write_clipped_grad) reinterpret_cast<float4*>(p.g)[i] = g;
+  }
+  for (int64_t i = 4 * n4 + tid; i < p.n; i += nthr) {
+    float w = p.p[i], g = p.g[i], m = p.m[i], v = p.v[i];
+    upd(w, g, m, v);
+    p.p[i] = w; p.m[i] = m; p.v[i] = v;
     if (p.write_clipped_grad) p.g[i] = g;
   }
 }
@@ -426,7 +454,7 @@ extern "C" int zs_pack_weight(const ZsPackWeight* p, void* stream) {
   int rc = pack_check(p);
   if (rc) return rc;
   if (p->taps <= PK_MAX_TAPS) {
-    const size_t lds = pk_lds_bytes(p->taps);
+    const size_t lds = PK_LDS_BYTES;
     if (p->dtype == ZS_F32) hipLaunchKernelGGL(pack_weight_tiled_kernel<float>, dim3(pk_tiles(*p)), dim3(PK_THREADS), lds, (hipStream_t)stream, *p);
     else hipLaunchKernelGGL(pack_weight_tiled_kernel<bf16_t>, dim3(pk_tiles(*p)), dim3(PK_THREADS), lds, (hipStream_t)stream, *p);
   } else {
@@ -435,7 +463,7 @@ extern "C" int zs_pack_weight(const ZsPackWeight* p, void* stream) {
   return zs_check_launch("zs_pack_weight");
 }
 
-extern "C" int zs_pack_weight_batch(const ZsPackWeight* jobs, int32_t n, void* stream) {
+extern "C" int zs_pack_weight_batch(const ZsPackWeight* jobs, int32_t n, int32_t max_blocks, void* stream) {
   ZS_REQUIRE(jobs && n > 0, "zs_pack_weight_batch: no jobs");
   for (int i = 0; i < n; ++i) {
     int rc = pack_check(jobs + i);
@@ -446,18 +474,20 @@ extern "C" int zs_pack_weight_batch(const ZsPackWeight* jobs, int32_t n, void* s
     const int m = n - i0 < PACK_BATCH ? n - i0 : PACK_BATCH;
     PackBatch b;
     memset(&b, 0, sizeof(b));
-    unsigned gx = 1;
-    int max_taps = 1;
+    int64_t total = 0;
     for (int i = 0; i < m; ++i) {
       b.job[i] = jobs[i0 + i];
       const ZsPackWeight& j = jobs[i0 + i];
-      const unsigned nb = j.taps <= PK_MAX_TAPS ? (unsigned)pk_tiles(j) : nblocks((int64_t)j.n_rows * j.n_cols, 4096);
-      if (nb > gx) gx = nb;
-      if (j.taps <= PK_MAX_TAPS && j.taps > max_taps) max_taps = j.taps;
+      b.tile_start[i] = (int32_t)total;
+      total += j.taps <= PK_MAX_TAPS ? (int64_t)pk_tiles(j) : (int64_t)nblocks((int64_t)j.n_rows * j.n_cols, 4096);
+      ZS_REQUIRE(total < (1ll << 30), "zs_pack_weight_batch: too many tiles");
     }
-    const size_t lds = pk_lds_bytes(max_taps);
-    if (jobs[0].dtype == ZS_F32) hipLaunchKernelGGL(pack_weight_batch_kernel<float>, dim3(gx, (unsigned)m), dim3(PK_THREADS), lds, (hipStream_t)stream, b);
-    else hipLaunchKernelGGL(pack_weight_batch_kernel<bf16_t>, dim3(gx, (unsigned)m), dim3(PK_THREADS), lds, (hipStream_t)stream, b);
+    for (int i = m; i <= PACK_BATCH; ++i) b.tile_start[i] = (int32_t)total;
+    b.n = m;
+    const unsigned gx = (unsigned)((max_blocks > 0 && total > max_blocks) ? max_blocks : total);
+    const size_t lds = PK_LDS_BYTES;
+    if (jobs[0].dtype == ZS_F32) hipLaunchKernelGGL(pack_weight_batch_kernel<float>, dim3(gx), dim3(PK_THREADS), lds, (hipStream_t)stream, b);
+    else hipLaunchKernelGGL(pack_weight_batch_kernel<bf16_t>, dim3(gx), dim3(PK_THREADS), lds, (hipStream_t)stream, b);
     int rc = zs_check_launch("zs_pack_weight_batch");
     if (rc) return rc;
   }
@@ -486,7 +516,8 @@ extern "C" int zs_copy_vec_batch(const ZsVecCopy* jobs, int32_t n, void* stream)
 extern "C" int zs_cast_rows(const ZsCastRows* p, void* stream) {
   ZS_REQUIRE(p && p->src && p->dst && p->rows > 0 && p->cols > 0 && p->fill_cols >= p->cols, "zs_cast_rows: bad args");
   ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_cast_rows: bad dtype");
-  ZS_DISPATCH(p->dtype, cast_rows_kernel, dim3(nblocks(p->rows * p->fill_cols, 4096)), dim3(NTE), stream, *p);
+  ZS_REQUIRE(!p->dst2 || p->fill_cols2 >= p->cols, "zs_cast_rows: fill_cols2 < cols");
+  ZS_DISPATCH(p->dtype, cast_rows_kernel, dim3(nblocks(p->rows * (p->dst2 && p->fill_cols2 > p->fill_cols ? p->fill_cols2 : p->fill_cols), 4096)), dim3(NTE), stream, *p);
   return zs_check_launch("zs_cast_rows");
 }
 
@@ -553,7 +584,9 @@ extern "C" int zs_sqnorm(const float* g, int64_t n, double* partial, float* out_
 extern "C" int zs_adam_clip(const ZsAdam* p, void* stream) {
   ZS_REQUIRE(p && p->p && p->g && p->m && p->v && p->n > 0, "zs_adam_clip: bad args");
   ZS_REQUIRE(p->step_ptr || (p->bc1 > 0.f && p->bc2 > 0.f), "zs_adam_clip: bias corrections");
-  hipLaunchKernelGGL(adam_kernel, dim3(nblocks(p->n, 4096)), dim3(NTE), 0, (hipStream_t)stream, *p);
+  unsigned nb = nblocks((p->n + 3) / 4, 4096);
+  if (p->max_blocks > 0 && nb > (unsigned)p->max_blocks) nb = (unsigned)p->max_blocks;
+  hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(NTE), 0, (hipStream_t)stream, *p);
   return zs_check_launch("zs_adam_clip");
 }
 

@@ -86,9 +86,8 @@ class EncoderEngine(_Taped):
         xin = c.act('e_xin' + tag, B, T, F)
         cat = c.act('e_cat' + tag, B, T, self.ncat)
         L.call('zs_cast_rows', 'ZsCastRows', st, dtype=c.dt, src=L.ptr(x), ld_src=F, src_f32=1, dst=xin.ptr(), ld_dst=xin.ld,
-               dst_f32=0, col_off=0, rows=B * T, cols=F, fill_cols=xin.ld, act=L.ZS_ACT_NONE)
-        L.call('zs_cast_rows', 'ZsCastRows', st, dtype=c.dt, src=L.ptr(x), ld_src=F, src_f32=1, dst=cat.ptr(), ld_dst=cat.ld,
-               dst_f32=0, col_off=7 * c1, rows=B * T, cols=F, fill_cols=cat.ld - 7 * c1, act=LRELU, slope=ns)   # :445-446
+               dst_f32=0, col_off=0, rows=B * T, cols=F, fill_cols=xin.ld, act=L.ZS_ACT_NONE,
+               dst2=cat.ptr(), ld_dst2=cat.ld, col_off2=7 * c1, fill_cols2=cat.ld - 7 * c1, act2=LRELU, slope2=ns)    # :445-446
         if c.overlap_wgrad and B * T >= 4096 and not (c.lane and os.environ.get('ZS_LANE_BANK_FORK', '0') != '1'):
             # the seven bank convs are independent and each fills half the chip at most (N = 128): run them side by side
             sts = fork_side(c.device)

@@ -62,6 +62,7 @@ class AEStep(object):
         self.lanes = max(1, int(os.environ.get('ZS_LANES', '1')))                # micro-batch lanes (see _seg_forward_decbwd)
         self._lane_loss, self._lane_part, self._lane_state = [], [], None
         self._graphs = {}            # (B, T, F) -> dict(graphs=[...], x=static x, c=static c)
+        self._statics = {}           # (B, T, F) -> (x, c) handed out by static_inputs()
         self._eager_calls = 0
         self.graph_warmup = 2        # eager steps (same launches) before the capture
 
@@ -238,7 +239,8 @@ class AEStep(object):
         b1, b2 = self.betas
         L.call('zs_adam_clip', 'ZsAdam', st, p=L.ptr(flat), g=L.ptr(gflat), m=L.ptr(o['m']), v=L.ptr(o['v']),
                n=flat.numel(), lr=self.lr, beta1=b1, beta2=b2, eps=1e-8, bc1=1.0, bc2=1.0, sumsq=L.ptr(o['sq']),
-               max_norm=self.max_grad_norm, write_clipped_grad=0, step_ptr=L.ptr(self._step_dev), grad_scale=self.reducer.scale)
+               max_norm=self.max_grad_norm, write_clipped_grad=0, step_ptr=L.ptr(self._step_dev), grad_scale=self.reducer.scale,
+               max_blocks=L.background_blocks())
         net.repack()
 
     def _early_decoder_update(self):
@@ -253,8 +255,8 @@ class AEStep(object):
             os_.wait_event(lane['ev_dec'])                         # every lane's decoder backward
         for ev in layers.side_events(self.device):
             os_.wait_event(ev)
-        with torch.cuda.stream(os_):
-            self._net_device_update('dec', self.Decoder)
+        with torch.cuda.stream(os_), L.background(int(os.environ.get('ZS_BG_BLOCKS', '0'))):
+            self._net_device_update('dec', self.Decoder)       # (ZS_BG_BLOCKS caps its grids: measured slower, 256: 12.1, 512: 11.7, 1024: 11.6 vs 11.46 ms uncapped)
         self._dec_updated = True
 
     def _optimizer_device_step(self):
@@ -278,12 +280,28 @@ class AEStep(object):
                 self._eager_calls += 1
                 self._counted_step_eager(x_btf, c, multi)
                 return self._loss
-            ent = self._capture(x_btf, c, multi)
+            ent = self._capture(x_btf, c, multi, statics=self._statics.get(key))
             self._graphs[key] = ent
-        ent['x'].copy_(x_btf, non_blocking=True)
-        ent['c'].copy_(c, non_blocking=True)
+        if x_btf.data_ptr() != ent['x'].data_ptr():        # (a loader that fills static_inputs() directly skips these copies)
+            ent['x'].copy_(x_btf, non_blocking=True)
+        if c.data_ptr() != ent['c'].data_ptr():
+            ent['c'].copy_(c, non_blocking=True)
         self._replay(ent, multi)
         return self._loss
+
+    def static_inputs(self, B, T, F):
+        """(x fp32 [B, T, F], c int64 [B]): the device buffers the captured step of this shape reads its batch from.  A loader that
+        writes the next batch straight into them and passes them to step() saves the device-to-device copy of the batch (67 MB
+        at B = 256) that step() otherwise makes in front of every replay.  Call before the first step of that shape."""
+        key = (B, T, F)
+        if key not in self._statics:
+            if key in self._graphs:
+                ent = self._graphs[key]
+                self._statics[key] = (ent['x'], ent['c'])
+            else:
+                self._statics[key] = (torch.zeros(B, T, F, dtype=torch.float32, device=self.device),
+                                      torch.zeros(B, dtype=torch.int64, device=self.device))
+        return self._statics[key]
 
     def _capture(self, x_btf, c, multi, statics=None, prefetch=None):
         """Capture the step on static inputs.  prefetch = (dst_x, src_x_pinned, dst_c, src_c_pinned): an H2D copy of the NEXT
