@@ -296,6 +296,10 @@ typedef struct {
                                     bit 0 (forward) / bit 1 (BPTT) into it and goes on with invalid data; the library never
                                     clears it.  The caller reads it at its own host sync points (Trainer.train: every logged
                                     loss; convert/encode: the end of a batch) and raises. */
+  /* optional broadcast riding on the recurrence's stores (append_emb, model/model.py:81-85,357: the third block of the
+   * concatenation the GRU output goes into): out[b][t][bcast_col + c] = bcast_vec[bcast_idx[b]][c] for c < 2H and every t.
+   * The persistent kernel is latency-bound and leaves HBM idle, so these 64 MB cost nothing there. */
+  const float* bcast_vec; int64_t bcast_ld; const int64_t* bcast_idx; int32_t bcast_col;
 } ZsGruFwd;
 size_t zs_gru_work_bytes(int32_t B, int32_t H);
 int zs_gru_fwd(const ZsGruFwd* p, void* stream);

@@ -359,6 +359,7 @@ struct GruPersistArgs {
   unsigned* status;              // optional caller-owned STICKY status word: bit 0 is OR-ed in on a timeout, never cleared here
   unsigned spin_limit;
   int B, T, H, rows_pad;
+  const float* bcast_vec; int64_t bcast_ld; const int64_t* bcast_idx; int bcast_col;   // ZsGruFwd.bcast_*
 };
 
 // 16-byte agent-scope (sc1: bypasses this CU's L1) load.  Inline asm so that all loads of a sweep are in flight together
@@ -437,6 +438,14 @@ __global__ __launch_bounds__(256) void gru_persist_fwd_kernel(const GruPersistAr
   const float b_r0 = bh[j], b_r1 = bh[j + 1], b_z0 = bh[H + j], b_z1 = bh[H + j + 1], b_n0 = bh[2 * H + j], b_n1 = bh[2 * H + j + 1];
   float hp[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
   bool dead = false;                                   // a sweep timed out: stop waiting (wave-uniform)
+  float bc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};           // broadcast values of this thread's (row, unit pair): constant over time
+  if (a.bcast_vec) {
+#pragma unroll
+    for (int pz = 0; pz < 2; ++pz) {
+      const int b = m0 + e_row + 16 * pz;
+      if (b < a.B) { const float* v = a.bcast_vec + a.bcast_idx[b] * a.bcast_ld + d * H + j; bc[pz][0] = v[0]; bc[pz][1] = v[1]; }
+    }
+  }
 
   for (int s = 0; s < T_; ++s) {
     const int t = d == 0 ? s : T_ - 1 - s;
@@ -534,6 +543,7 @@ __global__ __launch_bounds__(256) void gru_persist_fwd_kernel(const GruPersistAr
           T* gs = (T*)a.gates + (((int64_t)b * T_ + t) * 2 + d) * 4 * H + j;
           Pair<T>::st(gs, rg[0], rg[1]); Pair<T>::st(gs + H, zg[0], zg[1]); Pair<T>::st(gs + 2 * H, ng[0], ng[1]); Pair<T>::st(gs + 3 * H, hn[0], hn[1]);
         }
+        if (a.bcast_vec) Pair<T>::st((T*)a.out + ((int64_t)b * T_ + t) * a.ldo + a.bcast_col + d * H + j, bc[pz][0], bc[pz][1]);
       }
     }
     __syncthreads();                                   // `part` is free for the next step
@@ -777,6 +787,24 @@ extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
   float* gh = p->work;
   float* hstate = p->work + (size_t)2 * B * 3 * H;
   const char* outb = (const char*)p->out;
+  ZS_REQUIRE(!p->bcast_vec || (p->bcast_idx && (p->bcast_col * es) % 4 == 0), "zs_gru_fwd: bcast_idx / bcast_col");
+  bool bcast_pending = p->bcast_vec != nullptr;        // every path but the persistent kernel: a launch of its own, first
+  {
+    const int nrb0 = (B + 16 * RB - 1) / (16 * RB);
+    const int kstep0 = p->dtype == ZS_F32 ? 16 : 32;
+    const int per0 = (H % (4 * kstep0) == 0) ? H / (4 * kstep0) : 0;
+    if (p->whh_interleaved && H % 32 == 0 && gru_persist_enabled() && (per0 == 1 || per0 == 2 || per0 == 4) &&
+        (int64_t)(H / 32) * nrb0 * 2 <= gru_resident_limit() && T > 1)
+      bcast_pending = false;
+  }
+  if (bcast_pending) {
+    ZsAddRowvec r;
+    memset(&r, 0, sizeof(r));
+    r.dtype = p->dtype; r.vec = p->bcast_vec; r.vec_ld = p->bcast_ld; r.idx = p->bcast_idx;
+    r.out = (void*)(outb + (int64_t)p->bcast_col * es); r.ldo = p->ldo; r.B = B; r.T = T; r.C = 2 * H; r.fill_cols = 2 * H;
+    int rc = zs_add_rowvec(&r, stream);
+    if (rc) return rc;
+  }
   if (p->whh_interleaved && H % 32 == 0) {
     // persistent kernel: the time loop runs on the device (see gru_persist_fwd_kernel)
     const int nrb = (B + 16 * RB - 1) / (16 * RB);
@@ -793,6 +821,7 @@ extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
       a.err = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p->work) + zs_gru_work_bytes(B, H) - 256);   // reserved tail
       a.status = p->status; a.spin_limit = gru_spin_limit();
       a.B = B; a.T = T; a.H = H; a.rows_pad = nrb * 16 * RB;
+      a.bcast_vec = p->bcast_vec; a.bcast_ld = p->bcast_ld; a.bcast_idx = p->bcast_idx; a.bcast_col = p->bcast_col;
       if (hipMemsetAsync(p->work, 0, hx_bytes, (hipStream_t)stream) != hipSuccess || hipMemsetAsync(a.err, 0, 16, (hipStream_t)stream) != hipSuccess) {
         zs_set_error("zs_gru_fwd: memset failed");
         return ZS_ELAUNCH;

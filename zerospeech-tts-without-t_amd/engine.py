@@ -322,12 +322,11 @@ class DecoderEngine(_Taped):
         # child of a node on the parent's queue, so the critical chain must be captured first (measured: otherwise the GRU waits
         # for the whole fetch)
         post = c.hooks['dec_gru_fwd']() if c.hooks.get('dec_gru_fwd') else None
-        self.gru.fwd(xe, cat3, ch, gi, gates)                                                            # :352-356
+        # :352-356, and append_emb (:357) rides on the recurrence's stores (third block of cat3 = emb5[c_b] at every t)
+        self.gru.fwd(xe, cat3, ch, gi, gates, bcast=(None if self.fold5 else (emb[4], cidx, 2 * ch)))
         if post is not None:
             post()
         if not self.fold5:
-            L.call('zs_add_rowvec', 'ZsAddRowvec', st, dtype=c.dt, x=None, vec=L.ptr(emb[4]), vec_ld=ch, idx=L.ptr(cidx),
-                   out=cat3.ptr(2 * ch), ldo=cat3.ld, B=B, T=T, C=ch, fill_cols=ch)                       # :357 append_emb
             h5 = c.act('d_h5' + tag, B, T, ch)
             self.dense5.fwd(cat3, out=h5, act=LRELU, slope=ns)
             return self._fwd_tail(c, tp, h5, cat3, gates, xe, T, tag, B)

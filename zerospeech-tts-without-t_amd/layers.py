@@ -435,9 +435,10 @@ class GruLayer(object):
         n = L.lib().zs_gru_work_bytes(B, self.H)
         return self.ctx.f32('gru_work_%s' % self.name, (n + 3) // 4)
 
-    def fwd(self, X, out, out_col, gi, gates):
+    def fwd(self, X, out, out_col, gi, gates, bcast=None):
         """X: Act [B,T,Cin]; out: Act whose columns [out_col, out_col+2H) receive h (fwd ++ bwd);
-        gi: Act [B,T,6H] scratch; gates: raw tensor (T dtype, B*T*2*4H) or None."""
+        gi: Act [B,T,6H] scratch; gates: raw tensor (T dtype, B*T*2*4H) or None.
+        bcast = (vec fp32 [n, >= 2H], idx int64 [B], col): out[b, t, col:col+2H] = vec[idx[b], :2H] for every t (append_emb)."""
         c, H = self.ctx, self.H
         L.call('zs_gemm_conv', 'ZsGemmConv', c.stream, dtype=c.dt, A=X.ptr(), lda=X.ld, a_batch_stride=X.T * X.ld, B=X.B,
                T_in=X.T, T_out=X.T, taps=1, stride=1, pad_left=0, pad_mode=L.ZS_PAD_ZERO, gather=0, cin_pad=self.cin_pad,
@@ -448,7 +449,9 @@ class GruLayer(object):
                whh=L.ptr(self.whh_f), ldw=self.hh_ldw, n_pad=self.hh_npad, w_gstride=self.hh_npad * self.hh_ldw,
                bhh=L.ptr(self.bhh), bhh_gstride=3 * H, out=out.ptr(), ldo=out.ld, out_col=out_col,
                gates=L.ptr(gates) if gates is not None else None, work=L.ptr(work), work_bytes=work.numel() * 4,
-               whh_interleaved=int(self.fast), status=L.ptr(c.status))
+               whh_interleaved=int(self.fast), status=L.ptr(c.status),
+               bcast_vec=(L.ptr(bcast[0]) if bcast else None), bcast_ld=(bcast[0].shape[1] if bcast else 0),
+               bcast_idx=(L.ptr(bcast[1]) if bcast else None), bcast_col=(bcast[2] if bcast else 0))
 
     def check(self, B):
         """Test hook: raise if the last persistent pass over this layer's work buffer timed out (synchronises)."""
