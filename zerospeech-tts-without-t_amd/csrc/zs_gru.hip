@@ -520,28 +520,42 @@ __global__ __launch_bounds__(256) void gru_persist_fwd_kernel(const GruPersistAr
       return (part[0][rb][c][i][l] + part[1][rb][c][i][l]) + (part[2][rb][c][i][l] + part[3][rb][c][i][l]);
     };
     unsigned long long* hx_w = hx_d + (int64_t)(s & 1) * par_stride;
+    // Gate math of both row groups first, then both hand-off granules, then the ordinary stores: vmcnt counts loads and stores
+    // in one in-order counter, so a wait for this step's gate inputs placed behind a store (as the compiler must assume when
+    // loads are consumed after stores were issued) is a wait for that store's round trip -- on the critical path of the group.
+    float hv[2][2], rg[2][2], zg[2][2], ng[2][2], hn[2][2];
 #pragma unroll
     for (int pz = 0; pz < 2; ++pz) {
       const int rr = e_row + 16 * pz;
-      const int b = m0 + rr;
-      if (b < a.B) {
-        float hv[2], rg[2], zg[2], ng[2], hn[2], gi_r[2], gi_z[2], gi_n[2];
-        Pair<T>::cvt(q_r[pz], gi_r[0], gi_r[1]); Pair<T>::cvt(q_z[pz], gi_z[0], gi_z[1]); Pair<T>::cvt(q_n[pz], gi_n[0], gi_n[1]);
+      float gi_r[2], gi_z[2], gi_n[2];
+      Pair<T>::cvt(q_r[pz], gi_r[0], gi_r[1]); Pair<T>::cvt(q_z[pz], gi_z[0], gi_z[1]); Pair<T>::cvt(q_n[pz], gi_n[0], gi_n[1]);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const float ghr = total(hh, rr, cc + e), ghz = total(2 + hh, rr, cc + e), ghn = total(4 + hh, rr, cc + e);
-          rg[e] = 1.f / (1.f + expf(-(gi_r[e] + (ghr + (e ? b_r1 : b_r0)))));
-          zg[e] = 1.f / (1.f + expf(-(gi_z[e] + (ghz + (e ? b_z1 : b_z0)))));
-          hn[e] = ghn + (e ? b_n1 : b_n0);
-          ng[e] = tanhf(gi_n[e] + rg[e] * hn[e]);
-          hv[e] = (1.f - zg[e]) * ng[e] + zg[e] * hp[pz][e];
-          hp[pz][e] = hv[e];
-        }
-        if (s + 1 < T_) Pair<T>::publish(hx_w + (int64_t)b * gpr, j, (unsigned)(s + 1), hv[0], hv[1]);    // first: the others wait for it
-        Pair<T>::st((T*)a.out + ((int64_t)b * T_ + t) * a.ldo + a.out_col + d * H + j, hv[0], hv[1]);
+      for (int e = 0; e < 2; ++e) {
+        const float ghr = total(hh, rr, cc + e), ghz = total(2 + hh, rr, cc + e), ghn = total(4 + hh, rr, cc + e);
+        rg[pz][e] = 1.f / (1.f + expf(-(gi_r[e] + (ghr + (e ? b_r1 : b_r0)))));
+        zg[pz][e] = 1.f / (1.f + expf(-(gi_z[e] + (ghz + (e ? b_z1 : b_z0)))));
+        hn[pz][e] = ghn + (e ? b_n1 : b_n0);
+        ng[pz][e] = tanhf(gi_n[e] + rg[pz][e] * hn[pz][e]);
+        hv[pz][e] = (1.f - zg[pz][e]) * ng[pz][e] + zg[pz][e] * hp[pz][e];
+        hp[pz][e] = hv[pz][e];
+      }
+    }
+    if (s + 1 < T_) {                                  // first: the others wait for these
+#pragma unroll
+      for (int pz = 0; pz < 2; ++pz) {
+        const int b = m0 + e_row + 16 * pz;
+        if (b < a.B) Pair<T>::publish(hx_w + (int64_t)b * gpr, j, (unsigned)(s + 1), hv[pz][0], hv[pz][1]);
+      }
+    }
+#pragma unroll
+    for (int pz = 0; pz < 2; ++pz) {
+      const int b = m0 + e_row + 16 * pz;
+      if (b < a.B) {
+        Pair<T>::st((T*)a.out + ((int64_t)b * T_ + t) * a.ldo + a.out_col + d * H + j, hv[pz][0], hv[pz][1]);
         if (a.gates) {
           T* gs = (T*)a.gates + (((int64_t)b * T_ + t) * 2 + d) * 4 * H + j;
-          Pair<T>::st(gs, rg[0], rg[1]); Pair<T>::st(gs + H, zg[0], zg[1]); Pair<T>::st(gs + 2 * H, ng[0], ng[1]); Pair<T>::st(gs + 3 * H, hn[0], hn[1]);
+          Pair<T>::st(gs, rg[pz][0], rg[pz][1]); Pair<T>::st(gs + H, zg[pz][0], zg[pz][1]);
+          Pair<T>::st(gs + 2 * H, ng[pz][0], ng[pz][1]); Pair<T>::st(gs + 3 * H, hn[pz][0], hn[pz][1]);
         }
         if (a.bcast_vec) Pair<T>::st((T*)a.out + ((int64_t)b * T_ + t) * a.ldo + a.bcast_col + d * H + j, bc[pz][0], bc[pz][1]);
       }
@@ -670,39 +684,50 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_kernel(const GruPersistBw
       return (part[0][c][i][l] + part[1][c][i][l]) + (part[2][c][i][l] + part[3][c][i][l]);
     };
     unsigned long long* dx_w = dx_d + (int64_t)(s & 1) * par_stride;
+    // gate backward of both row groups, then all hand-off granules, then the ordinary stores (see the forward kernel)
+    float dr_pre[2][2], dz_pre[2][2], dn_pre[2][2], dnr[2][2];
 #pragma unroll
     for (int pz = 0; pz < 2; ++pz) {
       const int rr = e_row + 8 * pz;
-      const int b = m0 + rr;
-      if (b < a.B) {
-        float dr_pre[2], dz_pre[2], dn_pre[2], dnr[2], w_r[2], w_z[2], w_n[2], w_hn[2], w_do[2], w_hp[2];
-        Pair<T>::cvt(q_r[pz], w_r[0], w_r[1]); Pair<T>::cvt(q_z[pz], w_z[0], w_z[1]); Pair<T>::cvt(q_n[pz], w_n[0], w_n[1]);
-        Pair<T>::cvt(q_hn[pz], w_hn[0], w_hn[1]); Pair<T>::cvt(q_do[pz], w_do[0], w_do[1]); Pair<T>::cvt(q_hp[pz], w_hp[0], w_hp[1]);
-        if (s == T_ - 1) w_hp[0] = w_hp[1] = 0.f;
+      float w_r[2], w_z[2], w_n[2], w_hn[2], w_do[2], w_hp[2];
+      Pair<T>::cvt(q_r[pz], w_r[0], w_r[1]); Pair<T>::cvt(q_z[pz], w_z[0], w_z[1]); Pair<T>::cvt(q_n[pz], w_n[0], w_n[1]);
+      Pair<T>::cvt(q_hn[pz], w_hn[0], w_hn[1]); Pair<T>::cvt(q_do[pz], w_do[0], w_do[1]); Pair<T>::cvt(q_hp[pz], w_hp[0], w_hp[1]);
+      if (s == T_ - 1) w_hp[0] = w_hp[1] = 0.f;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          float dh = w_do[e] + dhd[pz][e];
-          if (s > 0) dh += total(hh, rr, cc + e);
-          const float r_ = w_r[e], z_ = w_z[e], n_ = w_n[e];
-          const float dn = dh * (1.f - z_);
-          const float dz = dh * (w_hp[e] - n_);
-          dhd[pz][e] = dh * z_;
-          dn_pre[e] = dn * (1.f - n_ * n_);
-          dr_pre[e] = dn_pre[e] * w_hn[e] * r_ * (1.f - r_);
-          dz_pre[e] = dz * z_ * (1.f - z_);
-          dnr[e] = dn_pre[e] * r_;
-        }
-        if (s + 1 < T_) {                              // first: the group waits for these
+      for (int e = 0; e < 2; ++e) {
+        float dh = w_do[e] + dhd[pz][e];
+        if (s > 0) dh += total(hh, rr, cc + e);
+        const float r_ = w_r[e], z_ = w_z[e], n_ = w_n[e];
+        const float dn = dh * (1.f - z_);
+        const float dz = dh * (w_hp[e] - n_);
+        dhd[pz][e] = dh * z_;
+        dn_pre[pz][e] = dn * (1.f - n_ * n_);
+        dr_pre[pz][e] = dn_pre[pz][e] * w_hn[e] * r_ * (1.f - r_);
+        dz_pre[pz][e] = dz * z_ * (1.f - z_);
+        dnr[pz][e] = dn_pre[pz][e] * r_;
+      }
+    }
+    if (s + 1 < T_) {                                  // first: the group waits for these
+#pragma unroll
+      for (int pz = 0; pz < 2; ++pz) {
+        const int b = m0 + e_row + 8 * pz;
+        if (b < a.B) {
           unsigned long long* xr = dx_w + (int64_t)b * gpr;
-          Pair<T>::publish(xr, j, (unsigned)(s + 1), dr_pre[0], dr_pre[1]);
-          Pair<T>::publish(xr, H + j, (unsigned)(s + 1), dz_pre[0], dz_pre[1]);
-          Pair<T>::publish(xr, 2 * H + j, (unsigned)(s + 1), dnr[0], dnr[1]);
+          Pair<T>::publish(xr, j, (unsigned)(s + 1), dr_pre[pz][0], dr_pre[pz][1]);
+          Pair<T>::publish(xr, H + j, (unsigned)(s + 1), dz_pre[pz][0], dz_pre[pz][1]);
+          Pair<T>::publish(xr, 2 * H + j, (unsigned)(s + 1), dnr[pz][0], dnr[pz][1]);
         }
+      }
+    }
+#pragma unroll
+    for (int pz = 0; pz < 2; ++pz) {
+      const int b = m0 + e_row + 8 * pz;
+      if (b < a.B) {
         const int64_t row = (int64_t)b * T_ + t;
         T* gi = (T*)a.dgi + row * a.ldgi + (int64_t)d * 3 * H + j;
         T* gh = (T*)a.dgh + row * a.ldgh + (int64_t)d * 3 * H + j;
-        Pair<T>::st(gi, dr_pre[0], dr_pre[1]); Pair<T>::st(gi + H, dz_pre[0], dz_pre[1]); Pair<T>::st(gi + 2 * H, dn_pre[0], dn_pre[1]);
-        Pair<T>::st(gh, dr_pre[0], dr_pre[1]); Pair<T>::st(gh + H, dz_pre[0], dz_pre[1]); Pair<T>::st(gh + 2 * H, dnr[0], dnr[1]);
+        Pair<T>::st(gi, dr_pre[pz][0], dr_pre[pz][1]); Pair<T>::st(gi + H, dz_pre[pz][0], dz_pre[pz][1]); Pair<T>::st(gi + 2 * H, dn_pre[pz][0], dn_pre[pz][1]);
+        Pair<T>::st(gh, dr_pre[pz][0], dr_pre[pz][1]); Pair<T>::st(gh + H, dz_pre[pz][0], dz_pre[pz][1]); Pair<T>::st(gh + 2 * H, dnr[pz][0], dnr[pz][1]);
       }
     }
     __syncthreads();
