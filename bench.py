@@ -318,16 +318,38 @@ def resynth_main(args):
         out['cpu_baseline'] = {'value': 1.0 / dc, 'unit': 'utterances/s', 'cores': cores, 'kind': 'port',
                                'sample': 'oracle spectrogram2wav (Griffin-Lim n_iter=%d, numpy FFT) of ONE %d-frame utterance: %.2f s; the '
                                          'network forward is not included (the vocoder is >95 %% of the CPU path)' % (n_iter, d.shape[0], dc)}
-    print(json.dumps(out), flush=True)
+    emit_json(out)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 
+_JSON_FD = None
+
+
+def claim_stdout():
+    """The bench's stdout carries ONE JSON line.  Libraries write there too (RCCL prints a version banner on its first collective):
+    keep a private duplicate of the real stdout for the JSON line and point fd 1 at stderr for everything else."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_json(out):
+    line = (json.dumps(out) + '\n').encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        sys.exit(spawn_ranks(args))
+        sys.exit(spawn_ranks(args))                    # (the parent keeps its stdout as it is: rank 0 inherits it)
+    claim_stdout()
     if args.mode == 'resynth':
         return resynth_main(args)
     import zs_amd  # noqa: F401
@@ -478,7 +500,7 @@ def main():
         if B != 16:
             big = cpu_baseline(seg_len, F, E, ch, nspk, steps=1, batch=B)              # and the GPU configuration's
             out['cpu_baseline']['at_gpu_batch'] = {k: big[k] for k in ('value', 'unit', 'sample')}
-    print(json.dumps(out), flush=True)
+    emit_json(out)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
