@@ -149,18 +149,20 @@ __global__ void copy_vec_batch_kernel(const VecBatch b) {
 // ---- cast_rows -------------------------------------------------------------------------------------
 template <typename T>
 __global__ void cast_rows_kernel(const ZsCastRows p) {
+  // one wave per row at a time (no per-element 64-bit division: the element-indexed form ran at 2.8 TB/s)
   const int fc = (p.dst2 && p.fill_cols2 > p.fill_cols) ? p.fill_cols2 : p.fill_cols;
-  const int64_t total = p.rows * fc;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / fc;
-    const int c = (int)(i - r * fc);
-    float x = 0.f;
-    if (c < p.cols) x = p.src_f32 ? ((const float*)p.src)[r * p.ld_src + c] : ldT<T>(p.src, r * p.ld_src + c);
-    if (c < p.fill_cols) {
-      const float v = (p.act == ZS_ACT_LRELU) ? lrelu_f(x, p.slope) : x;
-      if (p.dst_f32) ((float*)p.dst)[r * p.ld_dst + p.col_off + c] = v; else stT<T>(p.dst, r * p.ld_dst + p.col_off + c, v);
+  const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+  const int64_t nw = (int64_t)gridDim.x * wpb;
+  for (int64_t r = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); r < p.rows; r += nw) {
+    for (int c = lane; c < fc; c += 64) {
+      float x = 0.f;
+      if (c < p.cols) x = p.src_f32 ? ((const float*)p.src)[r * p.ld_src + c] : ldT<T>(p.src, r * p.ld_src + c);
+      if (c < p.fill_cols) {
+        const float v = (p.act == ZS_ACT_LRELU) ? lrelu_f(x, p.slope) : x;
+        if (p.dst_f32) ((float*)p.dst)[r * p.ld_dst + p.col_off + c] = v; else stT<T>(p.dst, r * p.ld_dst + p.col_off + c, v);
+      }
+      if (p.dst2 && c < p.fill_cols2) stT<T>(p.dst2, r * p.ld_dst2 + p.col_off2 + c, (p.act2 == ZS_ACT_LRELU) ? lrelu_f(x, p.slope2) : x);
     }
-    if (p.dst2 && c < p.fill_cols2) stT<T>(p.dst2, r * p.ld_dst2 + p.col_off2 + c, (p.act2 == ZS_ACT_LRELU) ? lrelu_f(x, p.slope2) : x);
   }
 }
 
@@ -266,23 +268,24 @@ __global__ void mbv_bwd_kernel(const ZsMbvBwd p) {
 template <typename T>
 __global__ void l1_stage1_kernel(const ZsL1Loss p) {
   __shared__ float red[NTE / 64];
-  const int64_t total = p.rows * p.fill_cols;
   const float gs = p.grad_scale / ((float)p.rows * (float)p.F);
+  const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+  const int64_t nw = (int64_t)gridDim.x * wpb;
   float s = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / p.fill_cols;
-    const int c = (int)(i - r * p.fill_cols);
-    float g = 0.f;
-    if (c < p.F) {
-      const float xd = p.x_dec[r * p.ld_dec + c];
-      const float d = xd - p.x[r * p.ldx + c];
-      s += fabsf(d);
-      g = (d > 0.f ? gs : (d < 0.f ? -gs : 0.f)) * xd * (1.f - xd);
+  for (int64_t r = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); r < p.rows; r += nw) {      // one wave per row at a time
+    for (int c = lane; c < p.fill_cols; c += 64) {
+      float g = 0.f;
+      if (c < p.F) {
+        const float xd = p.x_dec[r * p.ld_dec + c];
+        const float d = xd - p.x[r * p.ldx + c];
+        s += fabsf(d);
+        g = (d > 0.f ? gs : (d < 0.f ? -gs : 0.f)) * xd * (1.f - xd);
+      }
+      if (p.dlogits) stT<T>(p.dlogits, r * p.ldg + c, g);
     }
-    if (p.dlogits) stT<T>(p.dlogits, r * p.ldg + c, g);
   }
   s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  if (lane == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) { float t = 0.f; for (int w = 0; w < NTE / 64; ++w) t += red[w]; p.partial[blockIdx.x] = t; }
 }
@@ -517,7 +520,7 @@ extern "C" int zs_cast_rows(const ZsCastRows* p, void* stream) {
   ZS_REQUIRE(p && p->src && p->dst && p->rows > 0 && p->cols > 0 && p->fill_cols >= p->cols, "zs_cast_rows: bad args");
   ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_cast_rows: bad dtype");
   ZS_REQUIRE(!p->dst2 || p->fill_cols2 >= p->cols, "zs_cast_rows: fill_cols2 < cols");
-  ZS_DISPATCH(p->dtype, cast_rows_kernel, dim3(nblocks(p->rows * (p->dst2 && p->fill_cols2 > p->fill_cols ? p->fill_cols2 : p->fill_cols), 4096)), dim3(NTE), stream, *p);
+  ZS_DISPATCH(p->dtype, cast_rows_kernel, dim3(nblocks(p->rows * 64, 2048)), dim3(NTE), stream, *p);
   return zs_check_launch("zs_cast_rows");
 }
 
@@ -562,7 +565,7 @@ extern "C" int zs_l1_loss(const ZsL1Loss* p, void* stream) {
   ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_l1_loss: bad dtype");
   ZsL1Loss q = *p;
   if (!q.dlogits || q.fill_cols < q.F) q.fill_cols = q.F;
-  const unsigned nb = nblocks(q.rows * q.fill_cols, 1024);
+  const unsigned nb = nblocks(q.rows * 64, 1024);
   ZS_DISPATCH(p->dtype, l1_stage1_kernel, dim3(nb), dim3(NTE), stream, q);
   int rc = zs_check_launch("zs_l1_loss.stage1");
   if (rc) return rc;
