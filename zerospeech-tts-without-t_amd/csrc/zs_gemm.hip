@@ -2131,6 +2131,7 @@ extern "C" int zs_set_option(const char* key, int value) {
   else if (key && !strcmp(key, "wgrad_slab_cost")) slot = &g_wgrad_slab_cost;
   else if (key && !strcmp(key, "wgrad_p8_waste")) slot = &g_wgrad_waste;
   if (key && !strcmp(key, "gru_persist")) return zs_gru_persist_option(value);
+  if (key && !strcmp(key, "gru_wide")) return zs_gru_wide_option(value);
   if (key && !strcmp(key, "gru_spin_limit")) return zs_gru_spin_limit_option(value);
   if (key && !strcmp(key, "gl_prefetch")) return zs_gl_prefetch_option(value);
   if (!slot) { zs_set_error("zs_set_option: unknown key %s", key ? key : "(null)"); return ZS_EINVAL; }

@@ -565,6 +565,164 @@ __global__ __launch_bounds__(256) void gru_persist_fwd_kernel(const GruPersistAr
 }
 
 // ------------------------------------------------------------------------------------------------
+// "Wide" persistent recurrence (bf16, H = 32 * KS in {128, 256, 512}): the same data-tagged granule hand-off, re-tiled so that
+// a time step has ONE workgroup barrier, no cross-wave reduction and a third of the exchange partners' data per wave.
+// A group of H/64 workgroups owns 16 batch rows of one direction for the whole sequence; workgroup `hc` owns 64 hidden units,
+// each of its 4 waves (one per SIMD: a 512-VGPR budget) 16 units x 3 gates over the FULL K = H -- its slice of W_hh, 3*KS
+// 16-byte fragments (192 VGPRs at H = 512), stays in registers.  Per step:
+//   sweep: the 256 threads fetch the granules of the other workgroups' h_{s-1} (16 rows x (H-64) units, KS/2-1 16-byte sc1
+//          loads per thread) until every tag matches and drop the payloads into an LDS image of h_{s-1} (the own 64 units were
+//          put there at the end of the previous step) | barrier | KS x 3 MFMAs 16x16x32 per wave, A fragments from LDS |
+//   gate math in the accumulator layout (row 4*(lane>>4)+i, unit lane&15: r, z, n of one unit are in the same lane) |
+//   publish h_s (granules, pairs of units through a DPP swap), then the ordinary stores, then the own units into the OTHER LDS image.
+// Two LDS images by step parity make the single barrier sufficient (the image written at the end of step s was last read before
+// the barrier of step s).  Against the 32x32 tiling above (6.3 us per step at H = 512): see tools/gru_bench.py.
+// ------------------------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256) void gru_wide_fwd_kernel(const GruPersistArgs a) {
+  constexpr int H = 32 * KS;
+  constexpr int NCH = KS / 2 - 1;                       // sweep loads per thread: 16 rows x (H - 64) units / 4 units / 256
+  constexpr int CPR = (H - 64) / 4;                     // 16-byte chunks (4 units) of the other workgroups per row
+  constexpr int PITCH = H * 2 + 16;                     // bytes per row of the LDS image
+  __shared__ __attribute__((aligned(16))) unsigned char himg[2][16 * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, r = lane & 15;
+  const int d = blockIdx.z, T_ = a.T;
+  const int m0 = blockIdx.y * 16;
+  const int u_wg = blockIdx.x * 64;                     // first unit of this workgroup
+  const int unit = u_wg + wave * 16 + r;                // this lane's unit in the accumulator layout
+  constexpr int gpr = H / 2;                            // granules per row
+  const int64_t par_stride = (int64_t)a.rows_pad * gpr;
+  unsigned long long* hx_d = a.hx + (int64_t)d * 2 * par_stride;
+
+  // W_hh rows of this wave: packed (gate-interleaved per 32 units) row of (gate g, unit u) = (u/32)*96 + g*32 + u%32
+  uint4 fb[KS][3];
+  {
+    const int u0 = u_wg + wave * 16;
+    const bf16_t* Wb = (const bf16_t*)a.whh + (int64_t)d * a.w_gstride + (int64_t)((u0 >> 5) * 96 + (u0 & 31) + r) * a.ldw + q * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int g = 0; g < 3; ++g) fb[ks][g] = *reinterpret_cast<const uint4*>(Wb + (int64_t)(32 * g) * a.ldw + ks * 32);
+  }
+  const float* bh = a.bhh + (int64_t)d * a.bhh_gstride;
+  const float b_r = bh[unit], b_z = bh[H + unit], b_n = bh[2 * H + unit];
+  // sweep chunks of this thread: chunk c = tid + 256 i -> (row, 4 units of another workgroup)
+  int ch_row[NCH > 0 ? NCH : 1], ch_unit[NCH > 0 ? NCH : 1];
+  bool ch_valid[NCH > 0 ? NCH : 1];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + 256 * i;
+    const int row = c / CPR, cu = (c - row * CPR) * 4;
+    ch_row[i] = row; ch_unit[i] = cu < u_wg ? cu : cu + 64;
+    ch_valid[i] = (m0 + row) < a.B;
+  }
+  float hp[4] = {0.f, 0.f, 0.f, 0.f};
+  float bc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.bcast_vec) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int b = m0 + 4 * q + i;
+      if (b < a.B) bc[i] = a.bcast_vec[a.bcast_idx[b] * a.bcast_ld + d * H + unit];
+    }
+  }
+  bool dead = false;
+
+  for (int s = 0; s < T_; ++s) {
+    const int t = d == 0 ? s : T_ - 1 - s;
+    // gate inputs of this step (no other workgroup writes them): in flight under the sweep
+    unsigned short q_g[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int b = min(m0 + 4 * q + i, a.B - 1);
+      const bf16_t* gi = (const bf16_t*)a.gi + ((int64_t)b * T_ + t) * a.ldgi + (int64_t)d * 3 * H + unit;
+      q_g[i][0] = gi[0]; q_g[i][1] = gi[H]; q_g[i][2] = gi[2 * H];
+    }
+    f32x4_t acc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    unsigned char* const img = &himg[s & 1][0];
+    if (s > 0) {
+      if constexpr (NCH > 0) {
+        const int64_t poff = (int64_t)((s - 1) & 1) * par_stride;
+        gu32x4_t g4[NCH];
+        unsigned spins = 0;
+        for (;;) {
+#pragma unroll
+          for (int i = 0; i < NCH; ++i)
+            load16_sc1_issue(g4[i], hx_d + poff + (int64_t)(m0 + ch_row[i]) * gpr + (ch_unit[i] >> 1));
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          bool ok = true;
+#pragma unroll
+          for (int i = 0; i < NCH; ++i) {
+            asm volatile("" : "+v"(g4[i]));
+            ok &= (((g4[i].y == (unsigned)s) & (g4[i].w == (unsigned)s)) | !ch_valid[i]);
+          }
+          if (__all(ok) || dead) break;
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > a.spin_limit) {
+            if (lane == 0) {
+              __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (a.status) __hip_atomic_fetch_or(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            dead = true;
+            break;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+          *reinterpret_cast<uint2*>(img + ch_row[i] * PITCH + ch_unit[i] * 2) = make_uint2(ch_valid[i] ? g4[i].x : 0u, ch_valid[i] ? g4[i].z : 0u);
+      }
+      __syncthreads();                                   // the image of h_{s-1} is complete (own units: end of step s-1)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const uint4 fa = *reinterpret_cast<const uint4*>(img + r * PITCH + q * 16 + ks * 64);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) Frag16<bf16_t>::mma(fa, fb[ks][g], acc[g]);
+      }
+    }
+    // gate math: lane owns (row 4q + i, unit) for i < 4
+    float hv[4], rg[4], zg[4], ng[4], hn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float gi_r = bf2f(q_g[i][0]), gi_z = bf2f(q_g[i][1]), gi_n = bf2f(q_g[i][2]);
+      rg[i] = 1.f / (1.f + expf(-(gi_r + (acc[0][i] + b_r))));
+      zg[i] = 1.f / (1.f + expf(-(gi_z + (acc[1][i] + b_z))));
+      hn[i] = acc[2][i] + b_n;
+      ng[i] = tanhf(gi_n + rg[i] * hn[i]);
+      hv[i] = (1.f - zg[i]) * ng[i] + zg[i] * hp[i];
+      hp[i] = hv[i];
+    }
+    if (s + 1 < T_) {                                    // hand-off first: the group waits for it.  Even lanes publish (unit, unit+1)
+      unsigned long long* hx_w = hx_d + (int64_t)(s & 1) * par_stride;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float nb = __shfl_xor(hv[i], 1, 64);
+        const int b = m0 + 4 * q + i;
+        if (!(lane & 1) && b < a.B) store_granule(hx_w + (int64_t)b * gpr + (unit >> 1), (unsigned)(s + 1), Pair<bf16_t>::pack(hv[i], nb));
+      }
+      unsigned char* const nimg = &himg[(s + 1) & 1][0];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<bf16_t*>(nimg + (4 * q + i) * PITCH + unit * 2) = f2bf(hv[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int b = m0 + 4 * q + i;
+      if (b < a.B) {
+        bf16_t* orow = (bf16_t*)a.out + ((int64_t)b * T_ + t) * a.ldo;
+        orow[a.out_col + d * H + unit] = f2bf(hv[i]);
+        if (a.gates) {
+          bf16_t* gs = (bf16_t*)a.gates + (((int64_t)b * T_ + t) * 2 + d) * 4 * H + unit;
+          gs[0] = f2bf(rg[i]); gs[H] = f2bf(zg[i]); gs[2 * H] = f2bf(ng[i]); gs[3 * H] = f2bf(hn[i]);
+        }
+        if (a.bcast_vec) orow[a.bcast_col + d * H + unit] = f2bf(bc[i]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Persistent BPTT, same hand-off: workgroup (hc, rb, dir) owns 32 hidden units x 32 rows.  Per step it needs dgh of the
 // previous BPTT step for its rows and ALL 3H gate columns (published by the H/32 workgroups of its group as granules),
 // multiplies by its 32 rows of W_hh^T (32 x 3H, register-resident: each wave keeps its quarter of K), adds dout and its
@@ -748,6 +906,12 @@ size_t gru_hx_bytes(int B, int H, int es) {
 }
 // options: relaxed atomics (zs_set_option may be called from any thread; a launch reads each knob once)
 std::atomic<int> g_gru_persist{-1};
+std::atomic<int> g_gru_wide{-1};
+bool gru_wide_enabled() {
+  int v = g_gru_wide.load(std::memory_order_relaxed);
+  if (v < 0) { const char* e = getenv("ZS_GRU_WIDE"); v = e ? atoi(e) : 1; g_gru_wide.store(v, std::memory_order_relaxed); }
+  return v != 0;
+}
 std::atomic<int> g_gru_spin_limit{-1};
 bool gru_persist_enabled() {
   int v = g_gru_persist.load(std::memory_order_relaxed);
@@ -774,6 +938,8 @@ int64_t gru_resident_limit() {
 
 }  // namespace
 
+// "gru_wide" knob of zs_set_option: the 16-row x 64-unit tiling of the persistent kernels (bf16, H in {128, 256, 512})
+int zs_gru_wide_option(int value) { const int old = gru_wide_enabled() ? 1 : 0; g_gru_wide.store(value ? 1 : 0, std::memory_order_relaxed); return old; }
 // "gru_persist" knob of zs_set_option
 int zs_gru_persist_option(int value) { const int old = gru_persist_enabled() ? 1 : 0; g_gru_persist.store(value ? 1 : 0, std::memory_order_relaxed); return old; }
 // "gru_spin_limit": sweeps a persistent GRU wave waits for its group before it gives up (tests force a timeout with 0)
@@ -821,6 +987,9 @@ extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
     if (p->whh_interleaved && H % 32 == 0 && gru_persist_enabled() && (per0 == 1 || per0 == 2 || per0 == 4) &&
         (int64_t)(H / 32) * nrb0 * 2 <= gru_resident_limit() && T > 1)
       bcast_pending = false;
+    if (p->whh_interleaved && gru_persist_enabled() && gru_wide_enabled() && p->dtype == ZS_BF16 && (H == 128 || H == 256 || H == 512) && T > 1 &&
+        (int64_t)(H / 64) * ((B + 15) / 16) * 2 <= gru_resident_limit())
+      bcast_pending = false;
   }
   if (bcast_pending) {
     ZsAddRowvec r;
@@ -836,7 +1005,10 @@ extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
     const int kstep = p->dtype == ZS_F32 ? 16 : 32;
     const int per = (H % (4 * kstep) == 0) ? H / (4 * kstep) : 0;
     const int64_t nwg = (int64_t)(H / 32) * nrb * 2;
-    if (gru_persist_enabled() && (per == 1 || per == 2 || per == 4) && nwg <= gru_resident_limit() && T > 1) {
+    const int nrb16 = (B + 15) / 16;
+    const bool wide = gru_persist_enabled() && gru_wide_enabled() && p->dtype == ZS_BF16 && (H == 128 || H == 256 || H == 512) && T > 1 &&
+                      (int64_t)(H / 64) * nrb16 * 2 <= gru_resident_limit();
+    if (wide || (gru_persist_enabled() && (per == 1 || per == 2 || per == 4) && nwg <= gru_resident_limit() && T > 1)) {
       GruPersistArgs a;
       memset(&a, 0, sizeof(a));
       a.gi = p->gi; a.ldgi = p->ldgi; a.whh = p->whh; a.ldw = p->ldw; a.w_gstride = p->w_gstride;
@@ -845,11 +1017,18 @@ extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
       a.hx = reinterpret_cast<unsigned long long*>(p->work);
       a.err = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p->work) + zs_gru_work_bytes(B, H) - 256);   // reserved tail
       a.status = p->status; a.spin_limit = gru_spin_limit();
-      a.B = B; a.T = T; a.H = H; a.rows_pad = nrb * 16 * RB;
+      a.B = B; a.T = T; a.H = H; a.rows_pad = wide ? nrb16 * 16 : nrb * 16 * RB;
       a.bcast_vec = p->bcast_vec; a.bcast_ld = p->bcast_ld; a.bcast_idx = p->bcast_idx; a.bcast_col = p->bcast_col;
       if (hipMemsetAsync(p->work, 0, hx_bytes, (hipStream_t)stream) != hipSuccess || hipMemsetAsync(a.err, 0, 16, (hipStream_t)stream) != hipSuccess) {
         zs_set_error("zs_gru_fwd: memset failed");
         return ZS_ELAUNCH;
+      }
+      if (wide) {
+        dim3 wgrid(H / 64, nrb16, 2);
+        if (H == 512) hipLaunchKernelGGL(gru_wide_fwd_kernel<16>, wgrid, dim3(256), 0, (hipStream_t)stream, a);
+        else if (H == 256) hipLaunchKernelGGL(gru_wide_fwd_kernel<8>, wgrid, dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(gru_wide_fwd_kernel<4>, wgrid, dim3(256), 0, (hipStream_t)stream, a);
+        return zs_check_launch("zs_gru_fwd.wide");
       }
       dim3 grid(H / 32, nrb, 2);
 #define ZS_GRU_PF(TT, PP) hipLaunchKernelGGL((gru_persist_fwd_kernel<TT, PP>), grid, dim3(256), 0, (hipStream_t)stream, a)
