@@ -396,6 +396,18 @@ template <> struct Pair<float> {
   }
 };
 
+// The same load in a form the compiler can see (raw buffer load, cache policy sc1, volatile): it inserts the counted waits
+// itself, so such loads may stay in flight across any amount of code -- the wide kernels request the next step's granules right
+// after their own hand-off.  (The inline-asm form above is only safe when the wait follows the issue directly: a register the
+// compiler believes defined may be copied before the data has arrived.)
+typedef __amdgpu_buffer_rsrc_t gru_rsrc_t;
+__device__ __forceinline__ gru_rsrc_t make_buffer_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ gu32x4_t load16_sc1(gru_rsrc_t rsrc, unsigned byte_off) {
+  return __builtin_bit_cast(gu32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, (int)(0x80000000u | 16u)));
+}
+
 constexpr unsigned GRU_SPIN_LIMIT = 1u << 21;   // default of the "gru_spin_limit" option
 
 template <typename T, int PER>     // PER = k-steps (of Frag16<T>::KSTEP) per wave: H = 4 * PER * KSTEP
@@ -582,18 +594,24 @@ template <int KS>
 __global__ __launch_bounds__(256) void gru_wide_fwd_kernel(const GruPersistArgs a) {
   constexpr int H = 32 * KS;
   constexpr int NCH = KS / 2 - 1;                       // sweep loads per thread: 16 rows x (H - 64) units / 4 units / 256
+  constexpr int NCHA = NCH > 0 ? NCH : 1;
   constexpr int CPR = (H - 64) / 4;                     // 16-byte chunks (4 units) of the other workgroups per row
   constexpr int PITCH = H * 2 + 16;                     // bytes per row of the LDS image
-  __shared__ __attribute__((aligned(16))) unsigned char himg[2][16 * PITCH];
+  __shared__ __attribute__((aligned(16))) unsigned char himg[2][16 * PITCH];      // h_{s-1}, by step parity
+  __shared__ __attribute__((aligned(16))) bf16_t gi_s[2][16][3][64];               // gate inputs of the step, by step parity
+  __shared__ __attribute__((aligned(16))) bf16_t out_s[2][5][16][64];              // h, r, z, n, hn of the step, by step parity
+  __shared__ __attribute__((aligned(16))) bf16_t bc_s[16][64];                     // broadcast values (constant over time)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, r = lane & 15;
   const int d = blockIdx.z, T_ = a.T;
   const int m0 = blockIdx.y * 16;
   const int u_wg = blockIdx.x * 64;                     // first unit of this workgroup
-  const int unit = u_wg + wave * 16 + r;                // this lane's unit in the accumulator layout
+  const int ul = wave * 16 + r;                         // this lane's unit inside the workgroup (accumulator layout)
+  const int unit = u_wg + ul;
   constexpr int gpr = H / 2;                            // granules per row
   const int64_t par_stride = (int64_t)a.rows_pad * gpr;
   unsigned long long* hx_d = a.hx + (int64_t)d * 2 * par_stride;
+  const gru_rsrc_t hx_rs = make_buffer_rsrc(hx_d, (unsigned)(2 * par_stride * 8));     // both parities of this direction
 
   // W_hh rows of this wave: packed (gate-interleaved per 32 units) row of (gate g, unit u) = (u/32)*96 + g*32 + u%32
   uint4 fb[KS][3];
@@ -608,57 +626,78 @@ __global__ __launch_bounds__(256) void gru_wide_fwd_kernel(const GruPersistArgs 
   const float* bh = a.bhh + (int64_t)d * a.bhh_gstride;
   const float b_r = bh[unit], b_z = bh[H + unit], b_n = bh[2 * H + unit];
   // sweep chunks of this thread: chunk c = tid + 256 i -> (row, 4 units of another workgroup)
-  int ch_row[NCH > 0 ? NCH : 1], ch_unit[NCH > 0 ? NCH : 1];
-  bool ch_valid[NCH > 0 ? NCH : 1];
+  int ch_row[NCHA], ch_unit[NCHA];
+  unsigned ch_off[NCHA];                                 // byte offset of the chunk's granules in one parity of hx_d
+  bool ch_valid[NCHA];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = tid + 256 * i;
     const int row = c / CPR, cu = (c - row * CPR) * 4;
     ch_row[i] = row; ch_unit[i] = cu < u_wg ? cu : cu + 64;
     ch_valid[i] = (m0 + row) < a.B;
+    ch_off[i] = (unsigned)(((int64_t)(m0 + row) * gpr + (ch_unit[i] >> 1)) * 8);
   }
+  const unsigned par_bytes = (unsigned)(par_stride * 8);
+  // cooperative 16-byte transfers (8 units each).  gate inputs: 16 rows x 3 gates x 8 chunks = 384 (thread: tid, tid + 256 < 384);
+  // outputs: 6 arrays (h, r, z, n, hn, broadcast) x 16 rows x 8 chunks = 768 (thread: tid + 256 k, k < 3)
+  auto gi_src = [&](int id, int t) -> const bf16_t* {
+    const int row = id / 24, rem = id - row * 24, g = rem >> 3, c = rem & 7;
+    const int b = min(m0 + row, a.B - 1);
+    return (const bf16_t*)a.gi + ((int64_t)b * T_ + t) * a.ldgi + (int64_t)d * 3 * H + g * H + u_wg + 8 * c;
+  };
+  auto gi_dst = [&](int par, int id) -> uint4* {
+    const int row = id / 24, rem = id - row * 24, g = rem >> 3, c = rem & 7;
+    return reinterpret_cast<uint4*>(&gi_s[par][row][g][8 * c]);
+  };
+  auto copy_out = [&](int par, int t) {                 // staged outputs of one step -> global, 16-byte stores
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int id = tid + 256 * k;
+      const int arr = id >> 7, rem = id & 127, row = rem >> 3, c = rem & 7;
+      const int b = m0 + row;
+      if (b >= a.B) continue;
+      if (arr == 0) {
+        *reinterpret_cast<uint4*>((bf16_t*)a.out + ((int64_t)b * T_ + t) * a.ldo + a.out_col + d * H + u_wg + 8 * c) =
+            *reinterpret_cast<const uint4*>(&out_s[par][0][row][8 * c]);
+      } else if (arr < 5) {
+        if (a.gates)
+          *reinterpret_cast<uint4*>((bf16_t*)a.gates + (((int64_t)b * T_ + t) * 2 + d) * 4 * H + (arr - 1) * H + u_wg + 8 * c) =
+              *reinterpret_cast<const uint4*>(&out_s[par][arr][row][8 * c]);
+      } else if (a.bcast_vec) {
+        *reinterpret_cast<uint4*>((bf16_t*)a.out + ((int64_t)b * T_ + t) * a.ldo + a.bcast_col + d * H + u_wg + 8 * c) =
+            *reinterpret_cast<const uint4*>(&bc_s[row][8 * c]);
+      }
+    }
+  };
   float hp[4] = {0.f, 0.f, 0.f, 0.f};
-  float bc[4] = {0.f, 0.f, 0.f, 0.f};
   if (a.bcast_vec) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int b = m0 + 4 * q + i;
-      if (b < a.B) bc[i] = a.bcast_vec[a.bcast_idx[b] * a.bcast_ld + d * H + unit];
+      const int b = min(m0 + 4 * q + i, a.B - 1);
+      bc_s[4 * q + i][ul] = f2bf(a.bcast_vec[a.bcast_idx[b] * a.bcast_ld + d * H + unit]);
     }
   }
+  // gate inputs of step 0 (later steps: fetched one step ahead)
+  uint4 gq0 = *reinterpret_cast<const uint4*>(gi_src(tid, d == 0 ? 0 : T_ - 1)), gq1 = make_uint4(0, 0, 0, 0);
+  if (tid < 128) gq1 = *reinterpret_cast<const uint4*>(gi_src(tid + 256, d == 0 ? 0 : T_ - 1));
+  gu32x4_t g4[NCHA];                                      // sweep loads of the coming step, issued right after the hand-off
   bool dead = false;
 
   for (int s = 0; s < T_; ++s) {
     const int t = d == 0 ? s : T_ - 1 - s;
-    // gate inputs of this step (no other workgroup writes them): in flight under the sweep
-    unsigned short q_g[4][3];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int b = min(m0 + 4 * q + i, a.B - 1);
-      const bf16_t* gi = (const bf16_t*)a.gi + ((int64_t)b * T_ + t) * a.ldgi + (int64_t)d * 3 * H + unit;
-      q_g[i][0] = gi[0]; q_g[i][1] = gi[H]; q_g[i][2] = gi[2 * H];
-    }
+    unsigned char* const img = &himg[s & 1][0];
     f32x4_t acc[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) acc[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    unsigned char* const img = &himg[s & 1][0];
     if (s > 0) {
       if constexpr (NCH > 0) {
-        const int64_t poff = (int64_t)((s - 1) & 1) * par_stride;
-        gu32x4_t g4[NCH];
+        // the granules of h_{s-1} (tag s, parity (s-1)&1) were requested at the end of the previous step
+        const unsigned poff = (unsigned)((s - 1) & 1) * par_bytes;
         unsigned spins = 0;
         for (;;) {
-#pragma unroll
-          for (int i = 0; i < NCH; ++i)
-            load16_sc1_issue(g4[i], hx_d + poff + (int64_t)(m0 + ch_row[i]) * gpr + (ch_unit[i] >> 1));
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
           bool ok = true;
 #pragma unroll
-          for (int i = 0; i < NCH; ++i) {
-            asm volatile("" : "+v"(g4[i]));
-            ok &= (((g4[i].y == (unsigned)s) & (g4[i].w == (unsigned)s)) | !ch_valid[i]);
-          }
+          for (int i = 0; i < NCH; ++i) ok &= (((g4[i].y == (unsigned)s) & (g4[i].w == (unsigned)s)) | !ch_valid[i]);
           if (__all(ok) || dead) break;
           __builtin_amdgcn_s_sleep(1);
           if (++spins > a.spin_limit) {
@@ -669,12 +708,24 @@ __global__ __launch_bounds__(256) void gru_wide_fwd_kernel(const GruPersistArgs 
             dead = true;
             break;
           }
+#pragma unroll
+          for (int i = 0; i < NCH; ++i) g4[i] = load16_sc1(hx_rs, poff + ch_off[i]);
         }
 #pragma unroll
         for (int i = 0; i < NCH; ++i)
           *reinterpret_cast<uint2*>(img + ch_row[i] * PITCH + ch_unit[i] * 2) = make_uint2(ch_valid[i] ? g4[i].x : 0u, ch_valid[i] ? g4[i].z : 0u);
       }
-      __syncthreads();                                   // the image of h_{s-1} is complete (own units: end of step s-1)
+    }
+    *gi_dst(s & 1, tid) = gq0;
+    if (tid < 128) *gi_dst(s & 1, tid + 256) = gq1;
+    __syncthreads();                                     // images of h_{s-1} and of this step's gate inputs are complete
+    if (s > 0) copy_out((s - 1) & 1, d == 0 ? s - 1 : T_ - s);      // the previous step's outputs leave as 16-byte stores
+    if (s + 1 < T_) {                                    // next step's gate inputs: in flight under this step
+      const int tn = d == 0 ? s + 1 : T_ - 2 - s;
+      gq0 = *reinterpret_cast<const uint4*>(gi_src(tid, tn));
+      if (tid < 128) gq1 = *reinterpret_cast<const uint4*>(gi_src(tid + 256, tn));
+    }
+    if (s > 0) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const uint4 fa = *reinterpret_cast<const uint4*>(img + r * PITCH + q * 16 + ks * 64);
@@ -686,7 +737,7 @@ __global__ __launch_bounds__(256) void gru_wide_fwd_kernel(const GruPersistArgs 
     float hv[4], rg[4], zg[4], ng[4], hn[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float gi_r = bf2f(q_g[i][0]), gi_z = bf2f(q_g[i][1]), gi_n = bf2f(q_g[i][2]);
+      const float gi_r = bf2f(gi_s[s & 1][4 * q + i][0][ul]), gi_z = bf2f(gi_s[s & 1][4 * q + i][1][ul]), gi_n = bf2f(gi_s[s & 1][4 * q + i][2][ul]);
       rg[i] = 1.f / (1.f + expf(-(gi_r + (acc[0][i] + b_r))));
       zg[i] = 1.f / (1.f + expf(-(gi_z + (acc[1][i] + b_z))));
       hn[i] = acc[2][i] + b_n;
@@ -702,24 +753,24 @@ __global__ __launch_bounds__(256) void gru_wide_fwd_kernel(const GruPersistArgs 
         const int b = m0 + 4 * q + i;
         if (!(lane & 1) && b < a.B) store_granule(hx_w + (int64_t)b * gpr + (unit >> 1), (unsigned)(s + 1), Pair<bf16_t>::pack(hv[i], nb));
       }
+      if constexpr (NCH > 0) {                           // ... and ask for the others' h_s at once: the round trip runs under the rest
+        const unsigned poff = (unsigned)(s & 1) * par_bytes;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) g4[i] = load16_sc1(hx_rs, poff + ch_off[i]);
+      }
       unsigned char* const nimg = &himg[(s + 1) & 1][0];
 #pragma unroll
       for (int i = 0; i < 4; ++i) *reinterpret_cast<bf16_t*>(nimg + (4 * q + i) * PITCH + unit * 2) = f2bf(hv[i]);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int b = m0 + 4 * q + i;
-      if (b < a.B) {
-        bf16_t* orow = (bf16_t*)a.out + ((int64_t)b * T_ + t) * a.ldo;
-        orow[a.out_col + d * H + unit] = f2bf(hv[i]);
-        if (a.gates) {
-          bf16_t* gs = (bf16_t*)a.gates + (((int64_t)b * T_ + t) * 2 + d) * 4 * H + unit;
-          gs[0] = f2bf(rg[i]); gs[H] = f2bf(zg[i]); gs[2 * H] = f2bf(ng[i]); gs[3 * H] = f2bf(hn[i]);
-        }
-        if (a.bcast_vec) orow[a.bcast_col + d * H + unit] = f2bf(bc[i]);
-      }
+      out_s[s & 1][0][4 * q + i][ul] = f2bf(hv[i]);
+      out_s[s & 1][1][4 * q + i][ul] = f2bf(rg[i]); out_s[s & 1][2][4 * q + i][ul] = f2bf(zg[i]);
+      out_s[s & 1][3][4 * q + i][ul] = f2bf(ng[i]); out_s[s & 1][4][4 * q + i][ul] = f2bf(hn[i]);
     }
   }
+  __syncthreads();
+  copy_out((T_ - 1) & 1, d == 0 ? T_ - 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------
