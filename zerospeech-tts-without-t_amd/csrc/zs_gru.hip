@@ -943,6 +943,186 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_kernel(const GruPersistBw
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide persistent BPTT (bf16, H = 32 * KS in {128, 256, 512}): the tiling and hand-off of gru_wide_fwd_kernel.  A group of H/64
+// workgroups owns 16 rows of one direction; a wave owns 16 hidden units over the FULL K = 3H of dh_prev = dgh W_hh (its rows of
+// W_hh^T: 3*KS fragments in registers, three accumulator chains by gate block); dgh of the previous BPTT step lives in an LDS
+// image [16][3H] filled from the others' granules (3 * (KS/2 - 1) 16-byte sc1 loads per thread, requested right after this
+// step's own hand-off) and from the own units.  Gate tape / dout / h_prev come in and dgi / dgh go out as staged 16-byte transfers.
+// ------------------------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256) void gru_wide_bwd_kernel(const GruPersistBwdArgs a) {
+  constexpr int H = 32 * KS;
+  constexpr int NCH = 3 * (KS / 2 - 1);                 // sweep loads per thread: 16 rows x 3 gates x (H - 64) units / 4 / 256
+  constexpr int NCHA = NCH > 0 ? NCH : 1;
+  constexpr int CPR = (H - 64) / 4;                     // 16-byte chunks (4 units) of the other workgroups per (row, gate)
+  constexpr int PITCH = 3 * H * 2 + 16;                 // bytes per row of the LDS image of dgh
+  __shared__ __attribute__((aligned(16))) unsigned char gimg[2][16 * PITCH];       // dgh of the previous BPTT step, by step parity
+  __shared__ __attribute__((aligned(16))) bf16_t in_s[2][6][16][64];                // r, z, n, hn, dout, h_prev of the step
+  __shared__ __attribute__((aligned(16))) bf16_t out_s[2][4][16][64];               // dr_pre, dz_pre, dn_pre, dn_pre*r of the step
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, r = lane & 15;
+  const int d = blockIdx.z, T_ = a.T;
+  const int m0 = blockIdx.y * 16;
+  const int u_wg = blockIdx.x * 64;
+  const int ul = wave * 16 + r;
+  const int unit = u_wg + ul;
+  constexpr int gpr = 3 * H / 2;                        // granules per row
+  const int64_t par_stride = (int64_t)a.rows_pad * gpr;
+  unsigned long long* dx_d = a.dx + (int64_t)d * 2 * par_stride;
+  const gru_rsrc_t dx_rs = make_buffer_rsrc(dx_d, (unsigned)(2 * par_stride * 8));
+  const unsigned par_bytes = (unsigned)(par_stride * 8);
+
+  uint4 fb[3 * KS];                                      // rows (unit) of W_hh^T, K = 3H contiguous
+  {
+    const bf16_t* Wb = (const bf16_t*)a.whh_t + (int64_t)d * a.w_gstride + (int64_t)(u_wg + wave * 16 + r) * a.ldw + q * 8;
+#pragma unroll
+    for (int kk = 0; kk < 3 * KS; ++kk) fb[kk] = *reinterpret_cast<const uint4*>(Wb + kk * 32);
+  }
+  int ch_row[NCHA], ch_col[NCHA];
+  unsigned ch_off[NCHA];
+  bool ch_valid[NCHA];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + 256 * i;
+    const int row = c / (3 * CPR), rem = c - row * (3 * CPR), g = rem / CPR, cu = (rem - g * CPR) * 4;
+    ch_row[i] = row; ch_col[i] = g * H + (cu < u_wg ? cu : cu + 64);
+    ch_valid[i] = (m0 + row) < a.B;
+    ch_off[i] = (unsigned)(((int64_t)(m0 + row) * gpr + (ch_col[i] >> 1)) * 8);
+  }
+  // cooperative 16-byte transfers (8 units each): 6 input arrays x 16 rows x 8 chunks = 768 = 3 per thread; outputs likewise
+  // (dgi: dr, dz, dn ; dgh: dr, dz, dn*r)
+  auto in_src = [&](int id, int s_) -> const bf16_t* {
+    const int arr = id >> 7, rem = id & 127, row = rem >> 3, c = rem & 7;
+    const int b = min(m0 + row, a.B - 1);
+    const int t = d == 0 ? T_ - 1 - s_ : s_;
+    if (arr < 4) return (const bf16_t*)a.gates + (((int64_t)b * T_ + t) * 2 + d) * 4 * H + arr * H + u_wg + 8 * c;
+    if (arr == 4) return (const bf16_t*)a.dout + ((int64_t)b * T_ + t) * a.ldd + a.dout_col + d * H + u_wg + 8 * c;
+    const int tp = s_ < T_ - 1 ? (d == 0 ? t - 1 : t + 1) : t;            // last BPTT step: h_prev = 0 (zeroed below)
+    return (const bf16_t*)a.out + ((int64_t)b * T_ + tp) * a.ldo + a.out_col + d * H + u_wg + 8 * c;
+  };
+  auto copy_out = [&](int par, int s_) {
+    const int t = d == 0 ? T_ - 1 - s_ : s_;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int id = tid + 256 * k;
+      const int arr = id >> 7, rem = id & 127, row = rem >> 3, c = rem & 7;     // arr 0..2: dgi r, z, n ; 3..5: dgh r, z, n
+      const int b = m0 + row;
+      if (b >= a.B) continue;
+      const int g = arr < 3 ? arr : arr - 3;
+      const int src = arr == 5 ? 3 : g;
+      bf16_t* base = arr < 3 ? (bf16_t*)a.dgi + ((int64_t)b * T_ + t) * a.ldgi : (bf16_t*)a.dgh + ((int64_t)b * T_ + t) * a.ldgh;
+      *reinterpret_cast<uint4*>(base + (int64_t)d * 3 * H + g * H + u_wg + 8 * c) = *reinterpret_cast<const uint4*>(&out_s[par][src][row][8 * c]);
+    }
+  };
+  uint4 gq[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) gq[k] = *reinterpret_cast<const uint4*>(in_src(tid + 256 * k, 0));
+  float dhd[4] = {0.f, 0.f, 0.f, 0.f};                   // direct carry dh * z of the previous BPTT step
+  bool dead = false;
+
+  for (int s = 0; s < T_; ++s) {
+    unsigned char* const img = &gimg[s & 1][0];
+    gu32x4_t g4[NCHA];
+    f32x4_t acc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
+      if constexpr (NCH > 0) {
+        // (requested here, not behind the previous hand-off as in the forward kernel: 21 x 4 registers held across the whole
+        // step push the W_hh^T fragments through the AGPRs -- measured 7.6 against 7.05 us per step for the 4-wave K split)
+        const unsigned poff = (unsigned)((s - 1) & 1) * par_bytes;
+        unsigned spins = 0;
+        for (;;) {
+#pragma unroll
+          for (int i = 0; i < NCH; ++i) g4[i] = load16_sc1(dx_rs, poff + ch_off[i]);
+          bool ok = true;
+#pragma unroll
+          for (int i = 0; i < NCH; ++i) ok &= (((g4[i].y == (unsigned)s) & (g4[i].w == (unsigned)s)) | !ch_valid[i]);
+          if (__all(ok) || dead) break;
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > a.spin_limit) {
+            if (lane == 0) {
+              __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (a.status) __hip_atomic_fetch_or(a.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            dead = true;
+            break;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+          *reinterpret_cast<uint2*>(img + ch_row[i] * PITCH + ch_col[i] * 2) = make_uint2(ch_valid[i] ? g4[i].x : 0u, ch_valid[i] ? g4[i].z : 0u);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int id = tid + 256 * k;
+      uint4 v = gq[k];
+      if ((id >> 7) == 5 && s == T_ - 1) v = make_uint4(0, 0, 0, 0);          // h_prev of the first time step is h0 = 0
+      *reinterpret_cast<uint4*>(&in_s[s & 1][id >> 7][(id & 127) >> 3][8 * (id & 7)]) = v;
+    }
+    __syncthreads();                                     // images of dgh_{s-1} and of this step's operands are complete
+    if (s > 0) copy_out((s - 1) & 1, s - 1);
+    if (s + 1 < T_) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) gq[k] = *reinterpret_cast<const uint4*>(in_src(tid + 256 * k, s + 1));
+    }
+    if (s > 0) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const uint4 fa = *reinterpret_cast<const uint4*>(img + r * PITCH + q * 16 + (g * KS + ks) * 64);
+          Frag16<bf16_t>::mma(fa, fb[g * KS + ks], acc[g]);
+        }
+    }
+    float dr_pre[4], dz_pre[4], dn_pre[4], dnr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 4 * q + i;
+      const float r_ = bf2f(in_s[s & 1][0][row][ul]), z_ = bf2f(in_s[s & 1][1][row][ul]), n_ = bf2f(in_s[s & 1][2][row][ul]);
+      const float hn_ = bf2f(in_s[s & 1][3][row][ul]), do_ = bf2f(in_s[s & 1][4][row][ul]), hp_ = bf2f(in_s[s & 1][5][row][ul]);
+      float dh = do_ + dhd[i];
+      if (s > 0) dh += (acc[0][i] + acc[1][i]) + acc[2][i];
+      const float dn = dh * (1.f - z_);
+      const float dz = dh * (hp_ - n_);
+      dhd[i] = dh * z_;
+      dn_pre[i] = dn * (1.f - n_ * n_);
+      dr_pre[i] = dn_pre[i] * hn_ * r_ * (1.f - r_);
+      dz_pre[i] = dz * z_ * (1.f - z_);
+      dnr[i] = dn_pre[i] * r_;
+    }
+    if (s + 1 < T_) {                                    // hand-off first; even lanes publish (unit, unit + 1) of the three gate blocks
+      unsigned long long* dx_w = dx_d + (int64_t)(s & 1) * par_stride;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float n0 = __shfl_xor(dr_pre[i], 1, 64), n1 = __shfl_xor(dz_pre[i], 1, 64), n2 = __shfl_xor(dnr[i], 1, 64);
+        const int b = m0 + 4 * q + i;
+        if (!(lane & 1) && b < a.B) {
+          unsigned long long* xr = dx_w + (int64_t)b * gpr;
+          store_granule(xr + (unit >> 1), (unsigned)(s + 1), Pair<bf16_t>::pack(dr_pre[i], n0));
+          store_granule(xr + ((H + unit) >> 1), (unsigned)(s + 1), Pair<bf16_t>::pack(dz_pre[i], n1));
+          store_granule(xr + ((2 * H + unit) >> 1), (unsigned)(s + 1), Pair<bf16_t>::pack(dnr[i], n2));
+        }
+      }
+      unsigned char* const nimg = &gimg[(s + 1) & 1][0];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bf16_t* row = reinterpret_cast<bf16_t*>(nimg + (4 * q + i) * PITCH);
+        row[unit] = f2bf(dr_pre[i]); row[H + unit] = f2bf(dz_pre[i]); row[2 * H + unit] = f2bf(dnr[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      out_s[s & 1][0][4 * q + i][ul] = f2bf(dr_pre[i]); out_s[s & 1][1][4 * q + i][ul] = f2bf(dz_pre[i]);
+      out_s[s & 1][2][4 * q + i][ul] = f2bf(dn_pre[i]); out_s[s & 1][3][4 * q + i][ul] = f2bf(dnr[i]);
+    }
+  }
+  __syncthreads();
+  copy_out((T_ - 1) & 1, T_ - 1);
+}
+
 inline unsigned gate_blocks(int64_t total) {
   int64_t b = (total + NTG - 1) / NTG;
   if (b > 2048) b = 2048;
@@ -1017,6 +1197,12 @@ extern "C" int zs_gru_check(const float* work, int32_t B, int32_t H, void* strea
   return ZS_OK;
 }
 
+// the wide kernels move gate inputs / outputs as 16-byte vectors
+static bool gru_wide_aligned(const ZsGruFwd* p) {
+  return (p->out_col % 8) == 0 && (p->ldo % 8) == 0 && (p->ldgi % 8) == 0 && ((uintptr_t)p->out % 16) == 0 && ((uintptr_t)p->gi % 16) == 0 &&
+         (!p->gates || ((uintptr_t)p->gates % 16) == 0) && (!p->bcast_vec || (p->bcast_col % 8) == 0);
+}
+
 extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
   ZS_REQUIRE(p && p->gi && p->whh && p->bhh && p->out && p->work, "zs_gru_fwd: null operand");
   ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_gru_fwd: bad dtype");
@@ -1039,7 +1225,7 @@ extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
         (int64_t)(H / 32) * nrb0 * 2 <= gru_resident_limit() && T > 1)
       bcast_pending = false;
     if (p->whh_interleaved && gru_persist_enabled() && gru_wide_enabled() && p->dtype == ZS_BF16 && (H == 128 || H == 256 || H == 512) && T > 1 &&
-        (int64_t)(H / 64) * ((B + 15) / 16) * 2 <= gru_resident_limit())
+        (int64_t)(H / 64) * ((B + 15) / 16) * 2 <= gru_resident_limit() && gru_wide_aligned(p))
       bcast_pending = false;
   }
   if (bcast_pending) {
@@ -1058,7 +1244,7 @@ extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
     const int64_t nwg = (int64_t)(H / 32) * nrb * 2;
     const int nrb16 = (B + 15) / 16;
     const bool wide = gru_persist_enabled() && gru_wide_enabled() && p->dtype == ZS_BF16 && (H == 128 || H == 256 || H == 512) && T > 1 &&
-                      (int64_t)(H / 64) * nrb16 * 2 <= gru_resident_limit();
+                      (int64_t)(H / 64) * nrb16 * 2 <= gru_resident_limit() && gru_wide_aligned(p);
     if (wide || (gru_persist_enabled() && (per == 1 || per == 2 || per == 4) && nwg <= gru_resident_limit() && T > 1)) {
       GruPersistArgs a;
       memset(&a, 0, sizeof(a));
@@ -1153,6 +1339,29 @@ extern "C" int zs_gru_bwd(const ZsGruBwd* p, void* stream) {
   const bool fast = (H % 32 == 0);
   if (fast && gru_persist_enabled() && T > 1) {
     const int nrb = (B + 15) / 16;                         // 16 rows x 64 units per workgroup
+    if (gru_wide_enabled() && p->dtype == ZS_BF16 && (H == 128 || H == 256 || H == 512) && (int64_t)(H / 64) * nrb * 2 <= gru_resident_limit() &&
+        (p->dout_col % 8) == 0 && (p->out_col % 8) == 0 && (p->ldd % 8) == 0 && (p->ldo % 8) == 0 && (p->ldgi % 8) == 0 && (p->ldgh % 8) == 0 &&
+        (((uintptr_t)p->dout | (uintptr_t)p->out | (uintptr_t)p->gates | (uintptr_t)p->dgi | (uintptr_t)p->dgh) % 16) == 0) {
+      GruPersistBwdArgs a;
+      memset(&a, 0, sizeof(a));
+      a.dout = p->dout; a.ldd = p->ldd; a.dout_col = p->dout_col; a.out = p->out; a.ldo = p->ldo; a.out_col = p->out_col;
+      a.gates = p->gates; a.whh_t = p->whh_t; a.ldw = p->ldw; a.w_gstride = p->w_gstride;
+      a.dgi = p->dgi; a.ldgi = p->ldgi; a.dgh = p->dgh; a.ldgh = p->ldgh;
+      const size_t dx_bytes = gru_hx_bytes(B, 3 * H, es);
+      a.dx = reinterpret_cast<unsigned long long*>(p->work);
+      a.err = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p->work) + zs_gru_work_bytes(B, H) - 256);
+      a.status = p->status; a.spin_limit = gru_spin_limit();
+      a.B = B; a.T = T; a.H = H; a.rows_pad = nrb * 16;
+      if (hipMemsetAsync(p->work, 0, dx_bytes, (hipStream_t)stream) != hipSuccess || hipMemsetAsync(a.err, 0, 16, (hipStream_t)stream) != hipSuccess) {
+        zs_set_error("zs_gru_bwd: memset failed");
+        return ZS_ELAUNCH;
+      }
+      dim3 wgrid(H / 64, nrb, 2);
+      if (H == 512) hipLaunchKernelGGL(gru_wide_bwd_kernel<16>, wgrid, dim3(256), 0, (hipStream_t)stream, a);
+      else if (H == 256) hipLaunchKernelGGL(gru_wide_bwd_kernel<8>, wgrid, dim3(256), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL(gru_wide_bwd_kernel<4>, wgrid, dim3(256), 0, (hipStream_t)stream, a);
+      return zs_check_launch("zs_gru_bwd.wide");
+    }
     const int kstep = p->dtype == ZS_F32 ? 16 : 32;
     const int perb = ((3 * H) % (4 * kstep) == 0 && H % (16 * BNT) == 0) ? (3 * H) / (4 * kstep) : 0;
     const int64_t nwg = (int64_t)(H / (16 * BNT)) * nrb * 2;
