@@ -50,6 +50,9 @@ const char* zs_last_error(void);
  *   "gru_persist" (ZS_GRU_PERSIST, 1): one persistent launch per GRU pass (forward and BPTT: the time loop runs on the
  *       device, W_hh stays in registers, h / dgh travel between workgroups as data-tagged 8-byte granules) when the grid fits
  *       one workgroup per CU and H allows it; 0 = one launch per time step
+ *   "gru_wide" (ZS_GRU_WIDE, 1): bf16, H in {128, 256, 512}: the persistent kernels in their 16-row x 64-unit tiling (a wave
+ *       owns 16 units over the full K, W_hh slice in registers, one barrier per step, h / dgh of the group in an LDS image);
+ *       0 = the 32 x 32 (forward) / 16 x 64 K-split (BPTT) tilings, which also serve fp32 and other H
  *   "gru_spin_limit" (ZS_GRU_SPIN_LIMIT, 2^21): granule sweeps a persistent GRU wave makes before it gives up on its group
  *       (sets the status word, see ZsGruFwd.status); 0 forces the timeout path (tests)
  * The knobs are process-wide atomics: they may be set from any thread; a launch reads each knob once.

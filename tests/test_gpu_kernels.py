@@ -410,18 +410,20 @@ def test_mbv_bit_exact_and_grad(zs):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('persist', [1, 0])
+@pytest.mark.parametrize('persist', ['wide', 'narrow', 0])
 @pytest.mark.parametrize('shape', [(3, 5, 24, 16), (2, 16, 32, 32), (70, 6, 64, 64), (5, 9, 40, 96), (40, 12, 48, 128), (33, 7, 32, 256),
                                    (64, 10, 64, 512)])
 def test_gru(zs, dtype, shape, persist):
     """Bidirectional GRU forward + BPTT + all parameter gradients vs. the oracle GRU under autograd; with the persistent
     time-loop kernels (where H and the grid size allow them) and with one launch per step."""
     L, layers = zs
-    old_persist = L.set_option('gru_persist', persist)
+    old_persist = L.set_option('gru_persist', 1 if persist else 0)
+    old_wide = L.set_option('gru_wide', 1 if persist == 'wide' else 0)      # bf16, H in {128, 256, 512}: 16 rows x 64 units tiling
     try:
         _gru_case(L, layers, dtype, shape)
     finally:
         L.set_option('gru_persist', old_persist)
+        L.set_option('gru_wide', old_wide)
 
 
 def _gru_case(L, layers, dtype, shape):
@@ -456,6 +458,16 @@ def _gru_case(L, layers, dtype, shape):
     torch.cuda.synchronize()
     got = cat.valid()[:, :, Cin:]
     _close('gru fwd', got, out, 4 * _tol(dtype))
+    if H % 4 == 0:
+        # append_emb riding on the recurrence (ZsGruFwd.bcast_*): a third block of the output rows = vec[idx[b]] at every t
+        vec = torch.randn(5, 2 * H, generator=g)
+        idx = torch.randint(0, 5, (B,), generator=g)
+        cat3 = ctx.act('cat3', B, T, Cin + 4 * H)
+        gru.fwd(X, cat3, Cin, gi, None, bcast=(vec.to(dev), idx.to(dev), Cin + 2 * H))
+        torch.cuda.synchronize()
+        v3 = cat3.valid()
+        _close('gru fwd (with broadcast)', v3[:, :, Cin:Cin + 2 * H], out, 4 * _tol(dtype))
+        _close('broadcast block', v3[:, :, Cin + 2 * H:], _round(vec, dtype)[idx].unsqueeze(1).expand(B, T, 2 * H), 1e-6)
     dcat = _to_act(layers, ctx, 'dcat', torch.cat([torch.zeros(B, T, Cin), dout], dim=2))
     dgi, dgh = ctx.act('dgi', B, T, 6 * H), ctx.act('dgh', B, T, 6 * H)
     dX = ctx.act('dX', B, T, Cin)
