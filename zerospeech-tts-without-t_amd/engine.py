@@ -221,7 +221,9 @@ class EncoderEngine(_Taped):
         self._in_bwd(da, y2, tp['st0'], dz, tp)
         self.conv2.wgrad(dz, cat)
         dcat = c.act('e_dcat' + tag, B, T, self.ncat)
-        self.conv2.dgrad(dz, T, dcat, dact_src=cat, slope=ns)
+        # only the conv bank's 7*c_h1 columns are consumed: the pass-through columns of the concatenation are the gradient w.r.t.
+        # the input spectrogram, which the reference computes and drops (utils.py:43-45) -- a third of this GEMM
+        self.conv2.dgrad(dz, T, dcat, dact_src=cat, slope=ns, n_cols=7 * c1)
         for i, l in enumerate(self.conv1s):
             l.wgrad(dcat.sub(i * c1, c1), xin)
 

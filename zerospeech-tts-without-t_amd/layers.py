@@ -287,16 +287,21 @@ class ConvLayer(object):
         L.call('zs_gemm_conv', 'ZsGemmConv', c.stream, **kw)
         return T_out
 
-    def dgrad(self, dY, T_x, out, dact_src=None, slope=0.0, add_src=None, out_f32=False, add_f32=False, colsum=None, out_cols=None):
+    def dgrad(self, dY, T_x, out, dact_src=None, slope=0.0, add_src=None, out_f32=False, add_f32=False, colsum=None, out_cols=None,
+              n_cols=None):
         """dY: Act [B,T_y,Cout] (ld >= cout_pad).  out: Act with B*(T_x+pad_l+pad_r) rows (padded domain; equals the
         input gradient when k == 1).  Optional epilogue: *lrelu'(dact_src), +add_src (both only meaningful for k == 1).
-        colsum = (fp32 pointer, ld, col0): per-sample column sums of the raw gradient, columns >= col0 (see colsum_ok)."""
+        colsum = (fp32 pointer, ld, col0): per-sample column sums of the raw gradient, columns >= col0 (see colsum_ok).
+        n_cols: only the first n_cols input channels' gradient is wanted (the rest is neither computed nor stored)."""
         c = self.ctx
         Tp = T_x + self.pad_l + self.pad_r
+        N, n_pad = self.Cin, self.n_pad_d
+        if n_cols is not None and n_cols < self.Cin:
+            N, n_pad = n_cols, min(self.n_pad_d, rup(n_cols, 256))
         kw = dict(dtype=c.dt, A=dY.ptr(), lda=dY.ld, a_batch_stride=dY.T * dY.ld, B=dY.B, T_in=dY.T, T_out=Tp, taps=self.k,
                   stride=self.stride, pad_left=0, pad_mode=L.ZS_PAD_ZERO, gather=1, cin_pad=self.cout_pad,
-                  W=L.ptr(self.wd), ldw=self.ldw_d, N=self.Cin, n_pad=self.n_pad_d, act=L.ZS_ACT_NONE, slope=slope,
-                  out=out.ptr(), ldc=out.ld, out_cols=(out_cols if out_cols is not None else min(out.cols, rup(self.Cin, 32))),
+                  W=L.ptr(self.wd), ldw=self.ldw_d, N=N, n_pad=n_pad, act=L.ZS_ACT_NONE, slope=slope,
+                  out=out.ptr(), ldc=out.ld, out_cols=(out_cols if out_cols is not None else min(out.cols, rup(N, 32))),
                   store_mode=L.ZS_STORE_ROWS, groups=1, out_f32=int(out_f32))
         if dact_src is not None:
             kw.update(dact_src=dact_src.ptr(), dact_ld=dact_src.ld)
