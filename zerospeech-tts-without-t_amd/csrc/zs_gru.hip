@@ -17,6 +17,10 @@ extern "C" size_t zs_gru_work_bytes(int32_t B, int32_t H);
 
 namespace {
 
+// The work buffer starts with a 256-byte header whose first word is the error word of the persistent kernels (set when a bounded
+// spin timed out; read by zs_gru_check): header and exchange granules are zeroed by ONE memset per launch.
+constexpr size_t GRU_WORK_HDR = 256;
+
 constexpr int NTG = 256;
 
 struct GateFwdArgs {
@@ -1183,12 +1187,12 @@ extern "C" size_t zs_gru_work_bytes(int32_t B, int32_t H) {
   return steps > hx ? steps : hx;
 }
 
-// Debug / test hook: read back the error word of the persistent kernels (set when a bounded spin timed out; it lives in the
-// reserved 256-byte tail of the work buffer, which the one-launch-per-step path never touches).  Synchronises.
+// Debug / test hook: read back the error word of the persistent kernels (set when a bounded spin timed out; the first word of the
+// work buffer's header, which the one-launch-per-step path never touches).  Synchronises.
 extern "C" int zs_gru_check(const float* work, int32_t B, int32_t H, void* stream) {
   ZS_REQUIRE(work && B > 0 && H > 0, "zs_gru_check: bad args");
   unsigned v = 0;
-  if (hipMemcpyAsync(&v, reinterpret_cast<const char*>(work) + zs_gru_work_bytes(B, H) - 256, sizeof(v), hipMemcpyDeviceToHost,
+  if (hipMemcpyAsync(&v, reinterpret_cast<const char*>(work), sizeof(v), hipMemcpyDeviceToHost,
                      (hipStream_t)stream) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
     zs_set_error("zs_gru_check: copy failed");
     return ZS_ELAUNCH;
@@ -1212,8 +1216,9 @@ extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
   const int kc = 128 / es;
   ZS_REQUIRE((p->out_col * es) % 16 == 0, "zs_gru_fwd: out_col alignment");
   const int B = p->B, T = p->T, H = p->H;
-  float* gh = p->work;
-  float* hstate = p->work + (size_t)2 * B * 3 * H;
+  float* const wbase = p->work + GRU_WORK_HDR / sizeof(float);
+  float* gh = wbase;
+  float* hstate = wbase + (size_t)2 * B * 3 * H;
   const char* outb = (const char*)p->out;
   ZS_REQUIRE(!p->bcast_vec || (p->bcast_idx && (p->bcast_col * es) % 4 == 0), "zs_gru_fwd: bcast_idx / bcast_col");
   bool bcast_pending = p->bcast_vec != nullptr;        // every path but the persistent kernel: a launch of its own, first
@@ -1251,12 +1256,12 @@ extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
       a.gi = p->gi; a.ldgi = p->ldgi; a.whh = p->whh; a.ldw = p->ldw; a.w_gstride = p->w_gstride;
       a.bhh = p->bhh; a.bhh_gstride = p->bhh_gstride; a.out = p->out; a.ldo = p->ldo; a.out_col = p->out_col; a.gates = p->gates;
       const size_t hx_bytes = gru_hx_bytes(B, H, es);
-      a.hx = reinterpret_cast<unsigned long long*>(p->work);
-      a.err = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p->work) + zs_gru_work_bytes(B, H) - 256);   // reserved tail
+      a.hx = reinterpret_cast<unsigned long long*>(wbase);
+      a.err = reinterpret_cast<unsigned*>(p->work);
       a.status = p->status; a.spin_limit = gru_spin_limit();
       a.B = B; a.T = T; a.H = H; a.rows_pad = wide ? nrb16 * 16 : nrb * 16 * RB;
       a.bcast_vec = p->bcast_vec; a.bcast_ld = p->bcast_ld; a.bcast_idx = p->bcast_idx; a.bcast_col = p->bcast_col;
-      if (hipMemsetAsync(p->work, 0, hx_bytes, (hipStream_t)stream) != hipSuccess || hipMemsetAsync(a.err, 0, 16, (hipStream_t)stream) != hipSuccess) {
+      if (hipMemsetAsync(p->work, 0, GRU_WORK_HDR + hx_bytes, (hipStream_t)stream) != hipSuccess) {
         zs_set_error("zs_gru_fwd: memset failed");
         return ZS_ELAUNCH;
       }
@@ -1333,7 +1338,8 @@ extern "C" int zs_gru_bwd(const ZsGruBwd* p, void* stream) {
   const int es = p->dtype == ZS_F32 ? 4 : 2;
   const int kc = 128 / es;
   const int B = p->B, T = p->T, H = p->H;
-  float* dhd = p->work + (size_t)2 * B * 3 * H;
+  float* const wbase = p->work + GRU_WORK_HDR / sizeof(float);
+  float* dhd = wbase + (size_t)2 * B * 3 * H;
   float* dhg = dhd + (size_t)2 * B * H;
   const char* dghb = (const char*)p->dgh;
   const bool fast = (H % 32 == 0);
@@ -1348,11 +1354,11 @@ extern "C" int zs_gru_bwd(const ZsGruBwd* p, void* stream) {
       a.gates = p->gates; a.whh_t = p->whh_t; a.ldw = p->ldw; a.w_gstride = p->w_gstride;
       a.dgi = p->dgi; a.ldgi = p->ldgi; a.dgh = p->dgh; a.ldgh = p->ldgh;
       const size_t dx_bytes = gru_hx_bytes(B, 3 * H, es);
-      a.dx = reinterpret_cast<unsigned long long*>(p->work);
-      a.err = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p->work) + zs_gru_work_bytes(B, H) - 256);
+      a.dx = reinterpret_cast<unsigned long long*>(wbase);
+      a.err = reinterpret_cast<unsigned*>(p->work);
       a.status = p->status; a.spin_limit = gru_spin_limit();
       a.B = B; a.T = T; a.H = H; a.rows_pad = nrb * 16;
-      if (hipMemsetAsync(p->work, 0, dx_bytes, (hipStream_t)stream) != hipSuccess || hipMemsetAsync(a.err, 0, 16, (hipStream_t)stream) != hipSuccess) {
+      if (hipMemsetAsync(p->work, 0, GRU_WORK_HDR + dx_bytes, (hipStream_t)stream) != hipSuccess) {
         zs_set_error("zs_gru_bwd: memset failed");
         return ZS_ELAUNCH;
       }
@@ -1372,11 +1378,11 @@ extern "C" int zs_gru_bwd(const ZsGruBwd* p, void* stream) {
       a.gates = p->gates; a.whh_t = p->whh_t; a.ldw = p->ldw; a.w_gstride = p->w_gstride;
       a.dgi = p->dgi; a.ldgi = p->ldgi; a.dgh = p->dgh; a.ldgh = p->ldgh;
       const size_t dx_bytes = gru_hx_bytes(B, 3 * H, es);
-      a.dx = reinterpret_cast<unsigned long long*>(p->work);
-      a.err = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p->work) + zs_gru_work_bytes(B, H) - 256);   // reserved tail
+      a.dx = reinterpret_cast<unsigned long long*>(wbase);
+      a.err = reinterpret_cast<unsigned*>(p->work);
       a.status = p->status; a.spin_limit = gru_spin_limit();
       a.B = B; a.T = T; a.H = H; a.rows_pad = nrb * 16;
-      if (hipMemsetAsync(p->work, 0, dx_bytes, (hipStream_t)stream) != hipSuccess || hipMemsetAsync(a.err, 0, 16, (hipStream_t)stream) != hipSuccess) {
+      if (hipMemsetAsync(p->work, 0, GRU_WORK_HDR + dx_bytes, (hipStream_t)stream) != hipSuccess) {
         zs_set_error("zs_gru_bwd: memset failed");
         return ZS_ELAUNCH;
       }
