@@ -66,3 +66,11 @@ for r in range(3):
     tf, tb = timed(fwd_only), timed(bwd_only)
     print('round %d: forward %.1f us (%.2f us/step)   BPTT %.1f us (%.2f us/step)' % (r, tf * 1e3, tf * 1e3 / T, tb * 1e3, tb * 1e3 / T))
 layers.check_status(dev)
+if os.environ.get('ZS_GRU_PROFILE_DUMP'):
+    w = g._work(B)
+    hdr = w[:64].view(torch.int64).cpu()
+    names = ['sweep', 'barrier', 'mfma', 'gate math', 'hand-off + staging']
+    tot = float(sum(int(hdr[8 + k]) for k in range(5)))
+    print('BPTT phases of one wave (cycle counter units per step, share):')
+    for k, n in enumerate(names):
+        print('  %-20s %8.0f  %4.1f %%' % (n, int(hdr[8 + k]) / T, 100.0 * int(hdr[8 + k]) / max(tot, 1.0)))

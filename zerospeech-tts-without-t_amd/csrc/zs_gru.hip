@@ -953,6 +953,9 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_kernel(const GruPersistBw
 // W_hh^T: 3*KS fragments in registers, three accumulator chains by gate block); dgh of the previous BPTT step lives in an LDS
 // image [16][3H] filled from the others' granules (3 * (KS/2 - 1) 16-byte sc1 loads per thread, requested right after this
 // step's own hand-off) and from the own units.  Gate tape / dout / h_prev come in and dgi / dgh go out as staged 16-byte transfers.
+// -DZS_GRU_PROFILE: one wave accumulates cycle counts per phase into the work header (tools/gru_bench.py, ZS_GRU_PROFILE_DUMP=1):
+// of 13.3 k cycles per step 33 % are the sweep, 16 % the barrier, 32 % reading the image (all four waves read all 48 KB of it:
+// 192 KB of LDS reads per step and CU) + MFMAs + W_hh^T fragments coming back from the AGPRs, 6 % gate math, 12 % hand-off + staging.
 // ------------------------------------------------------------------------------------------------
 template <int KS>
 __global__ __launch_bounds__(256) void gru_wide_bwd_kernel(const GruPersistBwdArgs a) {
@@ -1024,8 +1027,17 @@ __global__ __launch_bounds__(256) void gru_wide_bwd_kernel(const GruPersistBwdAr
   for (int k = 0; k < 3; ++k) gq[k] = *reinterpret_cast<const uint4*>(in_src(tid + 256 * k, 0));
   float dhd[4] = {0.f, 0.f, 0.f, 0.f};                   // direct carry dh * z of the previous BPTT step
   bool dead = false;
+#ifdef ZS_GRU_PROFILE
+  long long pc[6] = {0, 0, 0, 0, 0, 0}, pt0 = 0, pt1 = 0;
+#define ZS_PT(k) { pt1 = __builtin_readcyclecounter(); pc[k] += pt1 - pt0; pt0 = pt1; }
+#else
+#define ZS_PT(k)
+#endif
 
   for (int s = 0; s < T_; ++s) {
+#ifdef ZS_GRU_PROFILE
+    pt0 = __builtin_readcyclecounter();
+#endif
     unsigned char* const img = &gimg[s & 1][0];
     gu32x4_t g4[NCHA];
     f32x4_t acc[3];
@@ -1054,6 +1066,7 @@ __global__ __launch_bounds__(256) void gru_wide_bwd_kernel(const GruPersistBwdAr
             break;
           }
         }
+        ZS_PT(0)
 #pragma unroll
         for (int i = 0; i < NCH; ++i)
           *reinterpret_cast<uint2*>(img + ch_row[i] * PITCH + ch_col[i] * 2) = make_uint2(ch_valid[i] ? g4[i].x : 0u, ch_valid[i] ? g4[i].z : 0u);
@@ -1067,6 +1080,7 @@ __global__ __launch_bounds__(256) void gru_wide_bwd_kernel(const GruPersistBwdAr
       *reinterpret_cast<uint4*>(&in_s[s & 1][id >> 7][(id & 127) >> 3][8 * (id & 7)]) = v;
     }
     __syncthreads();                                     // images of dgh_{s-1} and of this step's operands are complete
+    ZS_PT(1)
     if (s > 0) copy_out((s - 1) & 1, s - 1);
     if (s + 1 < T_) {
 #pragma unroll
@@ -1074,13 +1088,17 @@ __global__ __launch_bounds__(256) void gru_wide_bwd_kernel(const GruPersistBwdAr
     }
     if (s > 0) {
 #pragma unroll
-      for (int g = 0; g < 3; ++g)
+      for (int ks = 0; ks < KS; ++ks)                    // the three accumulator chains (gate blocks of K) interleaved
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+        for (int g = 0; g < 3; ++g) {
           const uint4 fa = *reinterpret_cast<const uint4*>(img + r * PITCH + q * 16 + (g * KS + ks) * 64);
           Frag16<bf16_t>::mma(fa, fb[g * KS + ks], acc[g]);
         }
     }
+#ifdef ZS_GRU_PROFILE
+    asm volatile("s_nop 0" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]));
+#endif
+    ZS_PT(2)
     float dr_pre[4], dz_pre[4], dn_pre[4], dnr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1097,6 +1115,7 @@ __global__ __launch_bounds__(256) void gru_wide_bwd_kernel(const GruPersistBwdAr
       dz_pre[i] = dz * z_ * (1.f - z_);
       dnr[i] = dn_pre[i] * r_;
     }
+    ZS_PT(3)
     if (s + 1 < T_) {                                    // hand-off first; even lanes publish (unit, unit + 1) of the three gate blocks
       unsigned long long* dx_w = dx_d + (int64_t)(s & 1) * par_stride;
 #pragma unroll
@@ -1122,9 +1141,17 @@ __global__ __launch_bounds__(256) void gru_wide_bwd_kernel(const GruPersistBwdAr
       out_s[s & 1][0][4 * q + i][ul] = f2bf(dr_pre[i]); out_s[s & 1][1][4 * q + i][ul] = f2bf(dz_pre[i]);
       out_s[s & 1][2][4 * q + i][ul] = f2bf(dn_pre[i]); out_s[s & 1][3][4 * q + i][ul] = f2bf(dnr[i]);
     }
+    ZS_PT(4)
   }
   __syncthreads();
   copy_out((T_ - 1) & 1, T_ - 1);
+#ifdef ZS_GRU_PROFILE
+  if (blockIdx.x == 2 && blockIdx.y == 3 && d == 0 && tid == 0) {
+    long long* o = reinterpret_cast<long long*>(a.err) + 8;        // header bytes 64..
+    for (int k = 0; k < 5; ++k) o[k] = pc[k];
+  }
+#endif
+#undef ZS_PT
 }
 
 inline unsigned gate_blocks(int64_t total) {
