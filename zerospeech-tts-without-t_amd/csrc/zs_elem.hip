@@ -149,19 +149,37 @@ __global__ void copy_vec_batch_kernel(const VecBatch b) {
 // ---- cast_rows -------------------------------------------------------------------------------------
 template <typename T>
 __global__ void cast_rows_kernel(const ZsCastRows p) {
-  // one wave per row at a time (no per-element 64-bit division: the element-indexed form ran at 2.8 TB/s)
+  // one wave per row at a time (no per-element 64-bit division: the element-indexed form ran at 2.8 TB/s); a lane takes a PAIR of
+  // columns, so that the bf16 destinations get 4-byte stores where their offsets allow it
   const int fc = (p.dst2 && p.fill_cols2 > p.fill_cols) ? p.fill_cols2 : p.fill_cols;
   const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
   const int64_t nw = (int64_t)gridDim.x * wpb;
+  const bool pair1 = !p.dst_f32 && sizeof(T) == 2 && ((p.col_off | (int)(p.ld_dst & 1)) & 1) == 0 && (((uintptr_t)p.dst) & 3) == 0;
+  const bool pair2 = p.dst2 && sizeof(T) == 2 && ((p.col_off2 | (int)(p.ld_dst2 & 1)) & 1) == 0 && (((uintptr_t)p.dst2) & 3) == 0;
   for (int64_t r = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); r < p.rows; r += nw) {
-    for (int c = lane; c < fc; c += 64) {
-      float x = 0.f;
-      if (c < p.cols) x = p.src_f32 ? ((const float*)p.src)[r * p.ld_src + c] : ldT<T>(p.src, r * p.ld_src + c);
-      if (c < p.fill_cols) {
-        const float v = (p.act == ZS_ACT_LRELU) ? lrelu_f(x, p.slope) : x;
-        if (p.dst_f32) ((float*)p.dst)[r * p.ld_dst + p.col_off + c] = v; else stT<T>(p.dst, r * p.ld_dst + p.col_off + c, v);
+    for (int c = 2 * lane; c < fc; c += 128) {
+      float x[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        x[e] = (c + e < p.cols) ? (p.src_f32 ? ((const float*)p.src)[r * p.ld_src + c + e] : ldT<T>(p.src, r * p.ld_src + c + e)) : 0.f;
+      {
+        const float v0 = (p.act == ZS_ACT_LRELU) ? lrelu_f(x[0], p.slope) : x[0], v1 = (p.act == ZS_ACT_LRELU) ? lrelu_f(x[1], p.slope) : x[1];
+        if (pair1 && c + 1 < p.fill_cols) {
+          *reinterpret_cast<uint32_t*>((bf16_t*)p.dst + r * p.ld_dst + p.col_off + c) = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+        } else {
+          if (c < p.fill_cols) { if (p.dst_f32) ((float*)p.dst)[r * p.ld_dst + p.col_off + c] = v0; else stT<T>(p.dst, r * p.ld_dst + p.col_off + c, v0); }
+          if (c + 1 < p.fill_cols) { if (p.dst_f32) ((float*)p.dst)[r * p.ld_dst + p.col_off + c + 1] = v1; else stT<T>(p.dst, r * p.ld_dst + p.col_off + c + 1, v1); }
+        }
       }
-      if (p.dst2 && c < p.fill_cols2) stT<T>(p.dst2, r * p.ld_dst2 + p.col_off2 + c, (p.act2 == ZS_ACT_LRELU) ? lrelu_f(x, p.slope2) : x);
+      if (p.dst2) {
+        const float v0 = (p.act2 == ZS_ACT_LRELU) ? lrelu_f(x[0], p.slope2) : x[0], v1 = (p.act2 == ZS_ACT_LRELU) ? lrelu_f(x[1], p.slope2) : x[1];
+        if (pair2 && c + 1 < p.fill_cols2) {
+          *reinterpret_cast<uint32_t*>((bf16_t*)p.dst2 + r * p.ld_dst2 + p.col_off2 + c) = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+        } else {
+          if (c < p.fill_cols2) stT<T>(p.dst2, r * p.ld_dst2 + p.col_off2 + c, v0);
+          if (c + 1 < p.fill_cols2) stT<T>(p.dst2, r * p.ld_dst2 + p.col_off2 + c + 1, v1);
+        }
+      }
     }
   }
 }
@@ -272,16 +290,24 @@ __global__ void l1_stage1_kernel(const ZsL1Loss p) {
   const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
   const int64_t nw = (int64_t)gridDim.x * wpb;
   float s = 0.f;
+  const bool pair = p.dlogits && sizeof(T) == 2 && (p.ldg & 1) == 0 && (((uintptr_t)p.dlogits) & 3) == 0;
   for (int64_t r = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); r < p.rows; r += nw) {      // one wave per row at a time
-    for (int c = lane; c < p.fill_cols; c += 64) {
-      float g = 0.f;
-      if (c < p.F) {
-        const float xd = p.x_dec[r * p.ld_dec + c];
-        const float d = xd - p.x[r * p.ldx + c];
-        s += fabsf(d);
-        g = (d > 0.f ? gs : (d < 0.f ? -gs : 0.f)) * xd * (1.f - xd);
+    for (int c = 2 * lane; c < p.fill_cols; c += 128) {                                         // a lane takes a pair of columns
+      float g[2] = {0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        if (c + e < p.F) {
+          const float xd = p.x_dec[r * p.ld_dec + c + e];
+          const float d = xd - p.x[r * p.ldx + c + e];
+          s += fabsf(d);
+          g[e] = (d > 0.f ? gs : (d < 0.f ? -gs : 0.f)) * xd * (1.f - xd);
+        }
+      if (pair && c + 1 < p.fill_cols) {
+        *reinterpret_cast<uint32_t*>((bf16_t*)p.dlogits + r * p.ldg + c) = (uint32_t)f2bf(g[0]) | ((uint32_t)f2bf(g[1]) << 16);
+      } else if (p.dlogits) {
+        stT<T>(p.dlogits, r * p.ldg + c, g[0]);
+        if (c + 1 < p.fill_cols) stT<T>(p.dlogits, r * p.ldg + c + 1, g[1]);
       }
-      if (p.dlogits) stT<T>(p.dlogits, r * p.ldg + c, g);
     }
   }
   s = wave_sum(s);
