@@ -202,6 +202,41 @@ def test_config2_b256_graph_equals_eager(dev):
     assert torch.equal(ea, eb) and torch.equal(da, db)
 
 
+def test_static_input_buffers_equal_passed_tensors(dev):
+    """AEStep.static_inputs: a loader that writes the batch straight into the buffers the captured step reads (no device-to-device
+    copy in front of a replay, what bench.py does for its resident batch) gives the step passed its own tensors, bit for bit."""
+    from zs_amd import layers
+    from zs_amd.model import Decoder, Encoder
+    from zs_amd.trainer import AEStep
+    B, T, Fb, E, ch, nspk = 32, 128, 513, 1024, 1024, 102
+    res = []
+    for static in (False, True):
+        torch.manual_seed(0)
+        enc = Encoder(ns=0.01, dp=0.5, enc_size=E, seg_len=128, enc_mode='multilabel_binary', dtype='bf16').to(dev)
+        dec = Decoder(ns=0.01, c_in=E, c_h=ch, c_a=nspk, seg_len=128, dtype='bf16').to(dev)
+        ae = AEStep(enc, dec, lr=1e-4, max_grad_norm=5.0, use_graph=True)
+        g = torch.Generator().manual_seed(1)
+        batches = [((torch.rand(B, T, Fb, generator=g) * (1 - 1e-8) + 1e-8).to(dev), torch.randint(0, nspk, (B,), generator=g).to(dev))
+                   for _ in range(5)]
+        losses = []
+        if static:
+            xs, cs = ae.static_inputs(B, T, Fb)
+        for x, c in batches:
+            if static:
+                xs.copy_(x); cs.copy_(c)
+                losses.append(ae.step(xs, cs).item())
+            else:
+                losses.append(ae.step(x, c).item())
+        layers.check_status(dev)
+        res.append((losses, enc.flat_params()[0].clone(), dec.flat_params()[0].clone(), len(ae._graphs)))
+        del ae, enc, dec
+        torch.cuda.empty_cache()
+    (la, ea, da, na), (lb, eb, db, nb) = res
+    assert na == 1 and nb == 1
+    assert la == lb, (la, lb)
+    assert torch.equal(ea, eb) and torch.equal(da, db)
+
+
 def _config1_hps(tmp_path, **over):
     d = json.load(open(os.path.join(ROOT, 'hps', 'zerospeech_english_1024.json')))
     d.update(n_speakers=2, n_target_speakers=2, batch_size=16, enc_pretrain_iters=10, max_to_keep=3)
