@@ -7,7 +7,7 @@ config 2  train_ae, english hps with enc_size = emb_size = 1024, **B = 256, bf16
 config 1  16 synthetic segments, 2 speakers, 10 iterations through Trainer.train(mode='pretrain_AE') (the reference's own loop,
           trainer.py:320-347) with the host DataLoader -> DevicePrefetcher in front, log / checkpoint cadence, and
           main.main(['--train_ae', '--synthetic', ...]).
-config 3  (DDP) rehearsed on ONE GPU: two rank processes on cuda:0 over gloo drive the product AEStep -- three-graph step ==
+config 3  (DDP) rehearsed on ONE GPU: two rank processes on cuda:0 over gloo drive the product AEStep -- four-graph step ==
           eager step bit for bit, replicas stay bit-identical, and the 1/world-folded update equals a single-rank step on
           the global batch.
 
@@ -445,7 +445,7 @@ if rank == 0:
     out['norm_rel_err'] = [abs((s.item() ** 0.5) * 0.5 - s1.item() ** 0.5) / (s1.item() ** 0.5) for s, s1 in zip(sq, sq1)]
     out['param_err_over_lr'] = [((a - b).abs().max() / 1e-3).item() for a, b in zip(p_multi, [enc1.flat_params()[0], dec1.flat_params()[0]])]
 
-# (c) three-graph multi-rank step == eager multi-rank step, bit for bit; replicas stay identical
+# (c) four-graph multi-rank step == eager multi-rank step, bit for bit; replicas stay identical
 res = []
 for mode in ('graph', 'eager'):
     enc, dec = build(5)
@@ -463,7 +463,7 @@ for mode in ('graph', 'eager'):
     layers.check_status(dev)
     res.append((losses, enc.flat_params()[0].clone(), dec.flat_params()[0].clone(), sum(len(v['graphs']) for v in ae._graphs.values())))
 (la, ea, da, na), (lb, eb, db, nb) = res
-assert na == 3 and nb == 0, (na, nb)
+assert na == 4 and nb == 0, (na, nb)
 assert la == lb, (la, lb)
 assert torch.equal(ea, eb) and torch.equal(da, db), 'graph and eager multi-rank steps differ'
 for t in (ea, da):

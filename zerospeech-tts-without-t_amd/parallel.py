@@ -34,7 +34,7 @@ def world_size():
 
 def multi_rank():
     """True when the data-parallel code path is to be taken: more than one rank, or ZS_FORCE_MULTI=1 (a one-rank rehearsal of the
-    multi-rank step -- three hipGraphs with RCCL all-reduces between them -- on a single GPU)."""
+    multi-rank step -- four hipGraphs with RCCL all-reduces between them -- on a single GPU)."""
     return world_size() > 1 or (os.environ.get('ZS_FORCE_MULTI') == '1' and dist.is_available() and dist.is_initialized())
 
 
@@ -81,12 +81,18 @@ class GradReducer(object):
             chunk = flat[lo:min(n, lo + self.bucket_elems)]
             self.pending.append((chunk, None, dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True)))
 
-    def finish(self):
-        for dst, half, work in self.pending:
+    def mark(self):
+        """Number of collectives started so far (argument of finish(upto=...))."""
+        return len(self.pending)
+
+    def finish(self, upto=None):
+        """Make the current stream wait for the first `upto` pending collectives (all of them by default)."""
+        n = len(self.pending) if upto is None else min(upto, len(self.pending))
+        for dst, half, work in self.pending[:n]:
             work.wait()
             if half is not None:
                 dst.copy_(half)
-        self.pending = []
+        self.pending = self.pending[n:]
 
 
 def broadcast_params(nets, src=0):

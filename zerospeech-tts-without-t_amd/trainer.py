@@ -33,8 +33,9 @@ class AEStep(object):
     Graph mode (ZS_GRAPH=1, default): after two eager warm-up steps the ~600 kernel launches of a step are captured
     into hipGraphs and replayed, so the host cost per step is a handful of calls instead of ~15 ms of Python/ctypes
     launches.  Everything that changes from step to step lives in device memory (RNG seed, Adam step count:
-    zs_step_counters).  With more than one rank the step is three graphs (fwd + decoder bwd | encoder bwd | optimizer)
-    with the RCCL all-reduces launched eagerly between them, so the decoder's reduce still overlaps the encoder bwd."""
+    zs_step_counters).  With more than one rank the step is four graphs (fwd + decoder bwd | encoder bwd | decoder optimizer |
+    encoder optimizer) with the RCCL all-reduces launched eagerly between them: the decoder's reduce overlaps the encoder bwd, the
+    encoder's the decoder's optimizer."""
 
     def __init__(self, encoder, decoder, lr=1e-4, betas=(0.5, 0.9), max_grad_norm=5.0, use_graph=None):
         self.Encoder, self.Decoder = encoder, decoder
@@ -224,10 +225,17 @@ class AEStep(object):
             self.reducer.start(dec.flat_params()[1])
         elif self.early_dec_update:
             self._early_decoder_update()
+        n_dec = self.reducer.mark()
         self._seg_encbwd()
         if multi:
+            # the decoder's clip + Adam + re-pack run while the encoder's all-reduce is still in flight
             self.reducer.start(enc.flat_params()[1])
+            self.reducer.finish(upto=n_dec)
+            self._net_device_update('dec', self.Decoder)
             self.reducer.finish()
+            self._net_device_update('enc', self.Encoder)
+            self.adam_step += 1
+            return
         self._optimizer_device_step()
 
     def _net_device_update(self, name, net):
@@ -386,10 +394,16 @@ class AEStep(object):
             self._optimizer_device_step()
             self.adam_step = step0                             # capture does not execute: the caller counts the step
 
+        def seg3_dec():                                        # multi-rank: the optimizer in two graphs, so that the decoder's
+            self._net_device_update('dec', self.Decoder)       # update runs under the encoder's all-reduce
+
+        def seg3_enc():
+            self._net_device_update('enc', self.Encoder)
+
         pool = None
         # single rank: the fetch branch joins at the very END of the graph (wherever the executor schedules it, it then runs
         # beside the encoder's backward instead of holding it up)
-        segs = [lambda: (seg1(), self._seg_encbwd(), seg3(), join_prefetch())] if not multi else [seg1, self._seg_encbwd, seg3]
+        segs = [lambda: (seg1(), self._seg_encbwd(), seg3(), join_prefetch())] if not multi else [seg1, self._seg_encbwd, seg3_dec, seg3_enc]
         for seg in segs:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):   # other threads (RCCL watchdog) may call HIP
@@ -402,13 +416,16 @@ class AEStep(object):
         if not multi:
             ent['graphs'][0].replay()
         else:
-            g1, g2, g3 = ent['graphs']
+            g1, g2, g3d, g3e = ent['graphs']
             g1.replay()
             self.reducer.start(self.Decoder.flat_params()[1])
+            n_dec = self.reducer.mark()
             g2.replay()
             self.reducer.start(self.Encoder.flat_params()[1])
+            self.reducer.finish(upto=n_dec)
+            g3d.replay()                                       # decoder clip + Adam + re-pack under the encoder's all-reduce
             self.reducer.finish()
-            g3.replay()
+            g3e.replay()
         self.adam_step += 1
 
     def host_feeder(self, loader):
