@@ -161,13 +161,15 @@ class KernelEvents(object):
             return r
 
         def dgrad(self, dY, T_x, out, *a, **kw):
-            if not ke.enabled or not _p8_dispatch(dY.B * (T_x + self.pad_l + self.pad_r), self.Cin, self.n_pad_d):
+            n = kw.get('n_cols') or self.Cin                  # columns this launch really computes (ConvLayer.dgrad n_cols)
+            n_pad = self.n_pad_d if n == self.Cin else min(self.n_pad_d, (n + 255) // 256 * 256)
+            if not ke.enabled or not _p8_dispatch(dY.B * (T_x + self.pad_l + self.pad_r), n, n_pad):
                 return odgrad(self, dY, T_x, out, *a, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             r = odgrad(self, dY, T_x, out, *a, **kw)
             e.record()
-            ke.pairs.append((s, e, 2.0 * dY.B * dY.T * self.Cout * self.Cin * self.k))
+            ke.pairs.append((s, e, 2.0 * dY.B * dY.T * self.Cout * n * self.k))
             return r
 
         layers.ConvLayer.fwd, layers.ConvLayer.dgrad = fwd, dgrad
