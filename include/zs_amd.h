@@ -94,9 +94,10 @@ typedef struct {
   int32_t groups; int64_t a_gstride, w_gstride, out_gstride, bias_gstride;
   /* optional per-sample column sums of the value BEFORE dact_src / add_src (the per-sample part of nn.Embedding's backward
    * where an embedding row was added to this GEMM's input, model/model.py:319,336,353; finished by zs_emb_scatter):
-   *   colsum[b][n - colsum_col0] += sum_t value[b*T_out + t][n]      for colsum_col0 <= n < N
+   *   colsum[b][n - colsum_col0] += sum_t value[b*T_out + t][n]      for colsum_col0 <= n < N   (colsum_post: of `out`)
    * One owner per (b, n): plain read-modify-write, no atomics.  Needs T_out | 128 (whole samples per tile). */
   float* colsum; int64_t colsum_ld; int32_t colsum_col0;
+  int32_t colsum_post;             /* 1: sum the STORED value (after dact_src / add_src) instead */
 } ZsGemmConv;
 int zs_gemm_conv(const ZsGemmConv* p, void* stream);
 

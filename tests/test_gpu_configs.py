@@ -632,3 +632,39 @@ def test_folded_emb5_block_equals_the_literal_concatenation(dev, monkeypatch):
         scale = ref.abs().max().item()
         if scale > 1e-8:
             assert (res[1][1][k] - ref).abs().max().item() / scale < 2e-5, k
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_thin_emb5_gradient_equals_the_literal_block(dev, monkeypatch, dtype):
+    """ZS_THIN_EMB5 (default on where c_h is a multiple of 128): the input gradient of dense5's append_emb block as
+    (sum_t dz5[b,t]) W5e -- column sums of the STORED dz5 from the epilogue of the GEMM that produces it (ZsGemmConv.colsum_post),
+    times the block as a B-row GEMM -- against computing and column-summing the whole third block: every decoder gradient."""
+    from zs_amd import _lib as L
+    from zs_amd.layers import join_side
+    from zs_amd.model import Decoder
+    g = torch.Generator().manual_seed(9)
+    B, ch = 5, 128
+    bits = (torch.rand(B, 8, 16, generator=g) > 0.5).float()
+    cidx = torch.randint(0, 4, (B,), generator=g)
+    dl = torch.randn(B, 128, 80, generator=g) * 1e-3
+    res = []
+    for thin in ('0', '1'):
+        monkeypatch.setenv('ZS_THIN_EMB5', thin)
+        torch.manual_seed(1)
+        dec = Decoder(c_in=8, c_out=80, c_h=ch, c_a=4, ns=0.01, seg_len=128, dtype=dtype).to(dev)
+        dec.train()
+        eng = dec._engine()
+        xd = dec(bits.to(dev), cidx.to(dev))
+        dlog = eng.ctx.act('t_dl', B, 128, 80)
+        L.call('zs_cast_rows', 'ZsCastRows', eng.ctx.stream, dtype=eng.ctx.dt, src=L.ptr(dl.to(dev).contiguous()), ld_src=80, src_f32=1,
+               dst=dlog.ptr(), ld_dst=dlog.ld, dst_f32=0, col_off=0, rows=B * 128, cols=80, fill_cols=dlog.ld, act=L.ZS_ACT_NONE)
+        eng.backward(dlog)
+        join_side(dev)
+        torch.cuda.synchronize()
+        res.append((xd.clone(), {k: dec.grad_view(k).clone() for k, _ in dec.named_parameters()}))
+    tol = 2e-5 if dtype == 'fp32' else 1.5e-2
+    assert torch.equal(res[0][0], res[1][0])
+    for k, ref in res[0][1].items():
+        scale = ref.abs().max().item()
+        if scale > 1e-8:
+            assert (res[1][1][k] - ref).abs().max().item() / scale < tol, k

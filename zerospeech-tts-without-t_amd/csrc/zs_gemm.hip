@@ -112,6 +112,16 @@ __device__ __forceinline__ void epilogue_colsum(const ZsGemmConv& p, const float
     const float* q = sC + r0 * CPITCH + col;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int r = 0;
+    if (p.colsum_post && (p.dact_src || p.add_src)) {
+      // the stored value: * lrelu'(dact_src) + add_src, element by element (small shapes / fp32 reach this path)
+      for (; r < p.T_out; ++r) {
+        float v = q[r * CPITCH];
+        const int64_t mm = (int64_t)m + r;
+        if (p.dact_src) v *= dlrelu_f(p.dtype == ZS_F32 ? ((const float*)p.dact_src)[mm * p.dact_ld + n] : bf2f(((const bf16_t*)p.dact_src)[mm * p.dact_ld + n]), p.slope);
+        if (p.add_src) v += (p.add_f32 || p.dtype == ZS_F32) ? ((const float*)p.add_src)[mm * p.add_ld + n] : bf2f(((const bf16_t*)p.add_src)[mm * p.add_ld + n]);
+        a0 += v;
+      }
+    }
     for (; r + 4 <= p.T_out; r += 4) {
       a0 += q[(r + 0) * CPITCH]; a1 += q[(r + 1) * CPITCH]; a2 += q[(r + 2) * CPITCH]; a3 += q[(r + 3) * CPITCH];
     }
@@ -1100,8 +1110,9 @@ __device__ __forceinline__ void p8_regs_epilogue(const ZsGemmConv& p, f32x4_m (&
     }
   __syncthreads();
 
-  if (!HAS2 && p.colsum != nullptr) {
-    // per-sample column sums of the staged values (before mask / add): one thread per (column, half of the tile's samples);
+  const bool cs_post = !HAS2 && p.colsum != nullptr && p.colsum_post && (p.dact_src != nullptr || p.add_src != nullptr);
+  auto colsum_pass = [&]() {
+    // per-sample column sums of the staged values: one thread per (column, half of the tile's samples);
     // a tile holds whole samples (256 % T_out == 0), so every (sample, column) has one owner: plain += , no atomics
     const int ns = PBM / p.T_out;
     const int col = tid & 255, n = n0 + col, hs = tid >> 8;
@@ -1121,7 +1132,8 @@ __device__ __forceinline__ void p8_regs_epilogue(const ZsGemmConv& p, f32x4_m (&
         *d += (a0 + a1) + (a2 + a3);
       }
     }
-  }
+  };
+  if (!HAS2 && p.colsum != nullptr && !cs_post) colsum_pass();      // of the value before mask / add
 
   const int c8 = (tid & 31) * 8, r0 = tid >> 5;                     // 32 x 16-byte groups per row, 16 rows per pass
   const int n = n0 + c8;
@@ -1182,10 +1194,15 @@ __device__ __forceinline__ void p8_regs_epilogue(const ZsGemmConv& p, f32x4_m (&
             }
             const int64_t orow = sp ? 2 * (int64_t)m + hi : (int64_t)m;
             store8<bf16_t>(outp + orow * p.ldc + oc, v);
+            if (cs_post) store8<bf16_t>(sT + row * PT + c8, v);     // the stored value back into the staging tile (own slot)
           }
         }
       }
     }
+  }
+  if (cs_post) {                                                    // column sums of the STORED values (colsum_post)
+    __syncthreads();
+    colsum_pass();
   }
   if constexpr (HAS2) {
     __syncthreads();                                                // every thread is done with the first staging

@@ -394,14 +394,26 @@ class DecoderEngine(_Taped):
         self._embsum.zero_()
         self.linear.wgrad(dlogit, h5)
         dz5 = c.act('d_dz5' + tag, B, T, ch)
-        self.linear.dgrad(dlogit, T, dz5, dact_src=h5, slope=ns)
-        self.dense5.wgrad(dz5, cat3)
-        dcat3 = c.act('d_dcat3' + tag, B, T, (2 if self.fold5 else 3) * ch)
         # the embedding parts of the k = 1 data gradients (per-sample column sums) come out of the GEMM epilogues when whole
         # samples fit a tile (ZsGemmConv.colsum); otherwise a zs_grad_combine pass over the gradient computes them
         fuse = colsum_ok(T) and os.environ.get('ZS_FUSE_COLSUM', '1') == '1'
         slot = lambda k, col0=0: (L.ptr(self._embsum, k * B * ch), ch, col0)
-        if not self.fold5 and fuse:                                                          # d emb5 via append_emb: the third
+        # append_emb's block of dense5 (model/model.py:357) multiplies a vector that is constant over time, so its input gradient
+        # is only needed summed over t: sum_t (dz5[b,t] W5e) = (sum_t dz5[b,t]) W5e -- the column sums of dz5 (epilogue of the
+        # GEMM that produces it) times the block, a B-row GEMM, instead of a third of dense5's data gradient
+        thin5 = fuse and not self.fold5 and ch % 128 == 0 and os.environ.get('ZS_THIN_EMB5', '1') == '1'
+        self.linear.dgrad(dlogit, T, dz5, dact_src=h5, slope=ns, colsum=(slot(5) if thin5 else None), colsum_post=True)
+        self.dense5.wgrad(dz5, cat3)
+        dcat3 = c.act('d_dcat3' + tag, B, T, (2 if self.fold5 else 3) * ch)
+        if thin5:
+            self.dense5.dgrad(dz5, T, dcat3, n_cols=2 * ch)
+            s32 = Act(self._embsum, B, 1, ch, ch, 5 * B * ch)
+            sT = c.act('d_s5' + tag, B, 1, ch)
+            L.call('zs_cast_rows', 'ZsCastRows', c.stream, dtype=c.dt, src=s32.ptr(), ld_src=ch, src_f32=1, dst=sT.ptr(), ld_dst=sT.ld,
+                   dst_f32=0, col_off=0, rows=B, cols=ch, fill_cols=sT.ld, act=L.ZS_ACT_NONE)
+            slot4 = Act(self._embsum, B, 1, ch, ch, 4 * B * ch)
+            self.dense5.dgrad(sT, 1, slot4, add_src=slot4, out_f32=True, add_f32=True, n_cols=ch, n_off=2 * ch)
+        elif not self.fold5 and fuse:                                                        # d emb5 via append_emb: the third
             self.dense5.dgrad(dz5, T, dcat3, colsum=slot(4, 2 * ch), out_cols=2 * ch)        # column block is summed, not stored
         else:
             self.dense5.dgrad(dz5, T, dcat3)

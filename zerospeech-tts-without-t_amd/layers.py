@@ -288,19 +288,23 @@ class ConvLayer(object):
         return T_out
 
     def dgrad(self, dY, T_x, out, dact_src=None, slope=0.0, add_src=None, out_f32=False, add_f32=False, colsum=None, out_cols=None,
-              n_cols=None):
+              n_cols=None, n_off=0, colsum_post=False):
         """dY: Act [B,T_y,Cout] (ld >= cout_pad).  out: Act with B*(T_x+pad_l+pad_r) rows (padded domain; equals the
         input gradient when k == 1).  Optional epilogue: *lrelu'(dact_src), +add_src (both only meaningful for k == 1).
         colsum = (fp32 pointer, ld, col0): per-sample column sums of the raw gradient, columns >= col0 (see colsum_ok).
-        n_cols: only the first n_cols input channels' gradient is wanted (the rest is neither computed nor stored)."""
+        n_cols (, n_off): only the gradient of the n_cols input channels from n_off on is wanted (the rest is neither computed nor
+        stored; column 0 of `out` is channel n_off).  colsum_post: the column sums are taken of the stored value (after mask / add)."""
         c = self.ctx
         Tp = T_x + self.pad_l + self.pad_r
         N, n_pad = self.Cin, self.n_pad_d
-        if n_cols is not None and n_cols < self.Cin:
-            N, n_pad = n_cols, min(self.n_pad_d, rup(n_cols, 256))
+        if n_cols is not None and (n_cols < self.Cin or n_off):
+            N = n_cols
+            n_pad = rup(n_cols, 256) if n_off + rup(n_cols, 256) <= self.n_pad_d else rup(n_cols, 128)
+            if n_off + n_pad > self.n_pad_d:
+                raise ValueError('dgrad: channel block [%d, %d) does not fit the packed weight (%d rows)' % (n_off, n_off + n_cols, self.n_pad_d))
         kw = dict(dtype=c.dt, A=dY.ptr(), lda=dY.ld, a_batch_stride=dY.T * dY.ld, B=dY.B, T_in=dY.T, T_out=Tp, taps=self.k,
                   stride=self.stride, pad_left=0, pad_mode=L.ZS_PAD_ZERO, gather=1, cin_pad=self.cout_pad,
-                  W=L.ptr(self.wd), ldw=self.ldw_d, N=N, n_pad=n_pad, act=L.ZS_ACT_NONE, slope=slope,
+                  W=L.ptr(self.wd, n_off * self.ldw_d), ldw=self.ldw_d, N=N, n_pad=n_pad, act=L.ZS_ACT_NONE, slope=slope,
                   out=out.ptr(), ldc=out.ld, out_cols=(out_cols if out_cols is not None else min(out.cols, rup(N, 32))),
                   store_mode=L.ZS_STORE_ROWS, groups=1, out_f32=int(out_f32))
         if dact_src is not None:
@@ -308,7 +312,7 @@ class ConvLayer(object):
         if add_src is not None:
             kw.update(add_src=add_src.ptr(), add_ld=add_src.ld, add_f32=int(add_f32))
         if colsum is not None:
-            kw.update(colsum=colsum[0], colsum_ld=colsum[1], colsum_col0=colsum[2])
+            kw.update(colsum=colsum[0], colsum_ld=colsum[1], colsum_col0=colsum[2], colsum_post=int(colsum_post))
         L.call('zs_gemm_conv', 'ZsGemmConv', c.stream, **kw)
         return Tp
 
