@@ -2000,12 +2000,16 @@ struct Knob {
 };
 Knob g_wgrad_p8("ZS_WGRAD_P8", 1);
 Knob g_wgrad_wgs("ZS_WGRAD_WGS", 256);      // workgroups one weight-gradient launch aims for (split-K plan of the 256x256 kernel)
+// workgroups a 128x128 weight-gradient launch aims for.  768 (three per CU-pair slot) is best for a launch alone; the launches of
+// this kernel run four side by side (the conv bank's seven at the end of the step), where fewer, deeper splits write and
+// re-read less slab: 448 measured 10.93 against 10.98 ms/step (384-512 equal, 256 and 1024 worse)
+Knob g_wgrad_wgs128("ZS_WGRAD_WGS128", 448);
 Knob g_wgrad_slab_cost("ZS_WGRAD_SLAB_COST", 13);   // cost of one split's slab write + re-read in K-tile times
 Knob g_wgrad_waste("ZS_WGRAD_P8_WASTE", 135);       // 256x256 weight-gradient tiles only while padded/real output area <= this / 100
 
 struct WgradPlan { int p8, splits, tile, co_tiles, ci_tiles, cout_r, cin_r, rows_per_split; };
 
-// Split-K plan.  128x128 tiles (fp32, small outputs): ~768 workgroups.  256x256 ping-pong tiles (bf16): one workgroup per
+// Split-K plan.  128x128 tiles (fp32, small outputs): ~448 workgroups (wgrad_wgs128).  256x256 ping-pong tiles (bf16): one workgroup per
 // CU and round, each split pays a 256-KiB slab write + re-read (~13 K-tile times at 1/256 of HBM), so minimise
 // rounds x (K tiles per split + 13).
 WgradPlan wgrad_plan(const ZsGemmWgrad* p) {
@@ -2035,7 +2039,8 @@ WgradPlan wgrad_plan(const ZsGemmWgrad* p) {
     }
     w.splits = bs;
   } else {
-    int64_t sp = (768 + tiles - 1) / tiles;
+    const int64_t target = g_wgrad_wgs128.get() > 0 ? g_wgrad_wgs128.get() : 448;
+    int64_t sp = (target + tiles - 1) / tiles;
     int64_t maxs = (M + 255) / 256;
     if (sp > maxs) sp = maxs;
     if (sp > 64) sp = 64;
@@ -2145,6 +2150,7 @@ extern "C" int zs_set_option(const char* key, int value) {
   else if (key && !strcmp(key, "gemm_p8_min_tiles")) slot = &g_p8_min_tiles;
   else if (key && !strcmp(key, "wgrad_p8")) slot = &g_wgrad_p8;
   else if (key && !strcmp(key, "wgrad_wgs")) slot = &g_wgrad_wgs;
+  else if (key && !strcmp(key, "wgrad_wgs128")) slot = &g_wgrad_wgs128;
   else if (key && !strcmp(key, "wgrad_slab_cost")) slot = &g_wgrad_slab_cost;
   else if (key && !strcmp(key, "wgrad_p8_waste")) slot = &g_wgrad_waste;
   if (key && !strcmp(key, "gru_persist")) return zs_gru_persist_option(value);
