@@ -43,6 +43,8 @@ def parse():
                     help='resynth: BASELINE config 4 (test_encode + Griffin-Lim resynthesis of 64 utterances) instead of the headline train_ae step')
     ap.add_argument('--utts', type=int, default=64)
     ap.add_argument('--host-input', action='store_true', help='copy the batch from pinned host memory every step (PCIe-inclusive rate; never the headline value)')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='skip the secondary records of the train_ae line (bf16-vs-fp32 parity of the benchmarked model, BASELINE configs 4 and 5)')
     return ap.parse_args()
 
 
@@ -141,17 +143,20 @@ class KernelEvents(object):
     dispatches to the dominant kernel (gemm_conv_p8m16_kernel: the 256x256 ping-pong tile); the smaller layers go to the
     ring / 128x128 kernels and are not counted."""
 
-    def __init__(self):
+    def __init__(self, all_launches=False):
         self.pairs = []      # (start, end, flops)
         self.enabled = False
+        self.all = all_launches          # True: every zs_gemm_conv launch through ConvLayer, whatever kernel it dispatches to
+        self._orig = None
 
     def install(self):
         from zs_amd import layers
         ke = self
         ofwd, odgrad = layers.ConvLayer.fwd, layers.ConvLayer.dgrad
+        self._orig = (ofwd, odgrad)
 
         def fwd(self, A, *a, **kw):
-            if not ke.enabled or not _p8_dispatch(A.B * self.t_out(A.T), self.Cout, self.n_pad):
+            if not ke.enabled or not (ke.all or _p8_dispatch(A.B * self.t_out(A.T), self.Cout, self.n_pad)):
                 return ofwd(self, A, *a, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -163,7 +168,7 @@ class KernelEvents(object):
         def dgrad(self, dY, T_x, out, *a, **kw):
             n = kw.get('n_cols') or self.Cin                  # columns this launch really computes (ConvLayer.dgrad n_cols)
             n_pad = self.n_pad_d if n == self.Cin else min(self.n_pad_d, (n + 255) // 256 * 256)
-            if not ke.enabled or not _p8_dispatch(dY.B * (T_x + self.pad_l + self.pad_r), n, n_pad):
+            if not ke.enabled or not (ke.all or _p8_dispatch(dY.B * (T_x + self.pad_l + self.pad_r), n, n_pad)):
                 return odgrad(self, dY, T_x, out, *a, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -173,6 +178,12 @@ class KernelEvents(object):
             return r
 
         layers.ConvLayer.fwd, layers.ConvLayer.dgrad = fwd, dgrad
+
+    def uninstall(self):
+        from zs_amd import layers
+        if self._orig is not None:
+            layers.ConvLayer.fwd, layers.ConvLayer.dgrad = self._orig
+            self._orig = None
 
     def summary(self):
         tot_ms = sum(s.elapsed_time(e) for s, e, _ in self.pairs)
@@ -206,28 +217,23 @@ def spawn_ranks(args):
     return rc
 
 
-def resynth_main(args):
+def resynth_record(args, rank, world, dev, steps, warmup, cpu=True):
     """BASELINE config 4: test_encode + convert.py Griffin-Lim resynthesis of 64 utterances of U{200..700} frames on one MI355X
     (full-size english model, random weights, bf16 network, fp32 vocoder, n_iter = 300).  A "step" = the whole batch once:
     fragmenting, Encoder + Decoder over every fragment, de-normalisation, 300 Griffin-Lim iterations, de-emphasis, trim.
     Inputs resident on the host as the reference's loader hands them over (numpy spectrograms): the utterances/s here INCLUDE the
     host-side fragment logic and the H2D / D2H copies.  Multi-GPU: replicas over a sharded utterance list, no collective.
-    roofline: the dominant kernel gl_iter_kernel (one fused Griffin-Lim iteration): achieved = algorithmic FLOPs of the real
-    1024-point transforms (2 per frame and iteration, 2.5 N log2 N each: SURVEY 8(d)'s ~25 kFLOP per transform) / HIP-event time
-    of the zs_griffin_lim loop on the launch stream, against the fp32 vector peak (157.3 TFLOP/s): FFT / latency-bound."""
+    roofline: the dominant kernel gl_iter_kernel (one fused Griffin-Lim iteration per launch) is bound by the memory system: every
+    iteration streams the complex spectrogram of all utterances in and out (more than the 256 MiB Infinity Cache holds at 64
+    utterances).  achieved = ALGORITHMIC bytes per launch (per frame: 513 complex64 read + 513 complex64 written + 513 fp32
+    magnitudes read = 10.3 KB) / the HIP-event time of a launch on the launch stream, against 8 TB/s; the FLOP rate of the
+    transforms (2 real 1024-point FFTs per frame and iteration, 2.5 N log2 N each) is reported beside it.
+    Returns the record (rank 0) or None."""
     import tempfile
     import numpy as np
-    import zs_amd  # noqa: F401
     from zs_amd import convert as cv, layers, parallel
     from zs_amd.hps import hp, make_hps
     from zs_amd.trainer import Trainer
-    rank, world, local = parallel.init_from_env(os.environ.get('ZS_DIST_BACKEND', 'nccl'))
-    if world != args.gpus:
-        sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE is %d\n' % (args.gpus, world))
-        sys.exit(2)
-    dev = torch.device('cuda', local)
-    torch.cuda.set_device(dev)
-    os.environ['LOCAL_RANK'] = str(local)
     torch.manual_seed(1)
     hps = make_hps(enc_size=1024, emb_size=1024, n_speakers=102)
     tr = Trainer(hps, None, 'targeted_residual', 'multilabel_binary', log_dir=tempfile.mkdtemp(), dtype=args.dtype, device=dev)
@@ -260,14 +266,14 @@ def resynth_main(args):
             gl_ms.append(s.elapsed_time(e))
         return encs, decs, wavs
 
-    for _ in range(max(1, args.warmup)):
+    for _ in range(max(1, warmup)):
         run(False)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         encs, decs, wavs = run(True)
     torch.cuda.synchronize()
     if world > 1:
@@ -284,31 +290,33 @@ def resynth_main(args):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     if rank != 0:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
-        return
+        return None
     out_frames = int(sum(d.shape[0] for d in decs))
     n_utt = len(lens_all)
-    value = n_utt * args.steps / dt
+    value = n_utt * steps / dt
     gl = sum(gl_ms) / len(gl_ms) * 1e-3
     gl_traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'r02_resynth_pmc_traffic.json')
+    tpath = os.path.join(ROOT, 'profiles', GL_TRAFFIC_FILE)
     if os.path.exists(tpath) and args.utts == 64:
-        gl_traffic = json.load(open(tpath)).get('kernels', {}).get('gl_iter_kernel<false>', {}).get('traffic_bytes_per_launch')
+        kk = json.load(open(tpath)).get('kernels', {})
+        gl_traffic = next((v.get('traffic_bytes_per_launch') for k, v in kk.items() if k.startswith('gl_iter_kernel')), None)
     fl = out_frames * (2 * n_iter + 1) * 2.5 * 1024 * 10          # per rank-0 shard
+    by = out_frames * 513.0 * (8 + 8 + 4)                         # algorithmic bytes per launch: spectrum in + out, magnitudes in
+    launch_s = gl / (n_iter + 1)
     out = {'metric': 'utterances/sec (test_encode + Griffin-Lim resynthesis, 64 utterances of 200..700 frames, n_iter=300)',
-           'value': value, 'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-           'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+           'value': value, 'unit': 'utterances/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
+           'ms_per_step': 1e3 * dt / steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
            'dtype': 'f32 (vocoder) / %s (network)' % args.dtype, 'data': 'synthetic',
            'config': {'workload': 'BASELINE config 4: encode + decode (english hps, enc_size=1024, emb_size=1024) + spectrogram2wav '
                                   '(Griffin-Lim n_iter=%d, de-emphasis, trim) of %d utterances of U{200..700} frames per GPU, host '
                                   'fragmenting and copies included' % (n_iter, len(lens)), 'parallelism': 'replicas%d' % world},
-           'frames_per_s': float(sum(lens_all)) * args.steps / dt, 'encode_decode_ms': 1e3 * dt_enc, 'griffin_lim_ms': 1e3 * gl,
-           'roofline': {'bound': 'fft-latency (fp32 vector peak as the ceiling)', 'achieved': fl / gl / 1e12, 'peak': 157.3, 'unit': 'TFLOP/s',
-                        'frac': fl / gl / 1e12 / 157.3, 'traffic': gl_traffic, 'traffic_unit': 'bytes/launch (committed rocprofv3 --pmc passes of this command)',
+           'frames_per_s': float(sum(lens_all)) * steps / dt, 'encode_decode_ms': 1e3 * dt_enc, 'griffin_lim_ms': 1e3 * gl,
+           'roofline': {'bound': 'hbm', 'achieved': by / launch_s / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': by / launch_s / 8e12,
+                        'traffic': gl_traffic, 'traffic_unit': 'bytes/launch (committed rocprofv3 --pmc passes of this command)',
                         'kernel': 'gl_iter_kernel (one fused Griffin-Lim iteration per launch, %d launches per batch)' % (n_iter + 1),
-                        'avg_launch_ms': 1e3 * gl / (n_iter + 1), 'algorithmic_flop_per_launch': fl / (2 * n_iter + 1) * 2}}
-    if not args.no_cpu_baseline:
+                        'avg_launch_ms': 1e3 * launch_s, 'algorithmic_bytes_per_launch': by,
+                        'fft_tflops': fl / gl / 1e12, 'fft_frac_of_fp32_vector_peak': fl / gl / 1e12 / 157.3}}
+    if cpu:
         sys.path.insert(0, os.path.join(ROOT, 'oracle'))
         import zs_oracle as O      # CPU baseline beside the measurement only
         cores = cpu_share()
@@ -320,11 +328,140 @@ def resynth_main(args):
         out['cpu_baseline'] = {'value': 1.0 / dc, 'unit': 'utterances/s', 'cores': cores, 'kind': 'port',
                                'sample': 'oracle spectrogram2wav (Griffin-Lim n_iter=%d, numpy FFT) of ONE %d-frame utterance: %.2f s; the '
                                          'network forward is not included (the vocoder is >95 %% of the CPU path)' % (n_iter, d.shape[0], dc)}
-    emit_json(out)
+    del tr
+    torch.cuda.empty_cache()
+    return out
+
+
+def resynth_main(args):
+    import zs_amd  # noqa: F401
+    from zs_amd import parallel
+    rank, world, local = parallel.init_from_env(os.environ.get('ZS_DIST_BACKEND', 'nccl'))
+    if world != args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE is %d\n' % (args.gpus, world))
+        sys.exit(2)
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    os.environ['LOCAL_RANK'] = str(local)
+    out = resynth_record(args, rank, world, dev, args.steps, args.warmup, cpu=not args.no_cpu_baseline)
+    if out is not None:
+        emit_json(out)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
+
+def stage2_record(args, dev, iters=2, batch=128, cpu=True):
+    """BASELINE config 5 on one GPU: train_p / train_tgat (patchGAN stage), batch 128, bf16, english hps with enc_size = emb_size =
+    1024.  One "iteration" = n_patch_steps (5) discriminator steps (each with the WGAN-GP double backward) + one generator step +
+    the target-guided step (trainer.py:467-560).  roofline: the conv GEMM launches of one discriminator step (zs_gemm_conv through
+    ConvLayer.fwd / dgrad: the critic's forward, data-gradient and adjoint convolutions), HIP events on the launch stream."""
+    import tempfile
+    from zs_amd import layers
+    from zs_amd.hps import make_hps
+    from zs_amd.trainer import Trainer
+    hps = make_hps(enc_size=1024, emb_size=1024, batch_size=batch)
+    tr = Trainer(hps, None, hps.g_mode, hps.enc_mode, log_dir=tempfile.mkdtemp(), dtype=args.dtype, device=dev)
+    s2 = tr.stage2()
+    g = torch.Generator().manual_seed(0)
+    B = batch
+    x_s = torch.rand(B, 128, 513, generator=g).to(dev)
+    x_t = torch.rand(B, 128, 513, generator=g).to(dev)
+    c_t = torch.randint(hps.n_speakers - hps.n_target_speakers, hps.n_speakers, (B,), generator=g).to(dev)
+
+    def iteration():
+        for _ in range(hps.n_patch_steps):
+            r = s2.d_step(x_s, x_t, c_t)
+        r2 = s2.g_step(x_s, x_t, c_t)
+        lrec = s2.tg_step(x_t, c_t)
+        return r, r2, lrec
+
+    iteration()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        r, r2, lrec = iteration()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    layers.check_status(dev)
+    t1 = time.perf_counter(); s2.d_step(x_s, x_t, c_t); torch.cuda.synchronize(); td = time.perf_counter() - t1
+    t1 = time.perf_counter(); s2.g_step(x_s, x_t, c_t); torch.cuda.synchronize(); tg = time.perf_counter() - t1
+    ke = KernelEvents(all_launches=True)
+    ke.install()
+    ke.enabled = True
+    s2.d_step(x_s, x_t, c_t)
+    torch.cuda.synchronize()
+    ke.enabled = False
+    ke.uninstall()
+    fl, ms, n = ke.summary()
+    peak = 2500.0 if args.dtype == 'bf16' else 157.3
+    out = {'metric': 'frames/sec (train_tgat iteration: 5 D steps with WGAN-GP + 1 G step + target-guided step)', 'value': B * 128 / dt,
+           'unit': 'frames/s', 'ms_per_iteration': 1e3 * dt, 'd_step_ms': 1e3 * td, 'g_step_ms': 1e3 * tg, 'dtype': args.dtype, 'data': 'synthetic',
+           'config': {'workload': 'BASELINE config 5 on one GPU: patchGAN stage, english hps enc_size=1024 emb_size=1024, batch=%d' % B},
+           'w_dis': float(r['w_dis'].item()), 'gp': float(r['gp'].item()), 'loss_adv': float(r2['loss_adv'].item()), 'tg_rec': float(lrec.item()),
+           'peak_memory_gb': torch.cuda.max_memory_allocated() / 1e9,
+           'roofline': {'bound': 'mfma', 'achieved': fl / (ms * 1e-3) / 1e12 if ms else None, 'peak': peak, 'unit': 'TFLOP/s',
+                        'frac': (fl / (ms * 1e-3) / 1e12 / peak) if ms else None, 'traffic': None,
+                        'kernel': 'zs_gemm_conv launches of one discriminator step (forward, data-gradient and adjoint convolutions)',
+                        'launches_timed': n, 'gemm_ms_per_d_step': ms, 'gemm_tflop_per_d_step': fl / 1e12}}
+    if cpu:
+        sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+        import zs_oracle as O      # CPU baseline beside the measurement only
+        cores = cpu_share()
+        torch.set_num_threads(cores)
+        Bc = 2
+        sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in tr.PatchDiscriminator.state_dict().items()}
+        hp_ = dict(ns=hps.ns, seg_len=hps.seg_len, beta_dis=hps.beta_dis, beta_clf=hps.beta_clf, lambda_=hps.lambda_)
+        xt_c, xg_c = x_t[:Bc].permute(0, 2, 1).cpu().contiguous(), x_s[:Bc].permute(0, 2, 1).cpu().contiguous()
+        cc = (c_t[:Bc] - (hps.n_speakers - hps.n_target_speakers)).cpu()
+        t0 = time.perf_counter()
+        loss = O.patch_d_loss(sd, xt_c, xg_c, cc, torch.rand(Bc), hp_)[0]
+        loss.backward()
+        dc = time.perf_counter() - t0
+        out['cpu_baseline'] = {'value': Bc * 128 / (dc * hps.n_patch_steps), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+                               'sample': 'oracle discriminator step (3 critic forwards, WGAN-GP double backward, all gradients) on %d segments: '
+                                         '%.2f s; x %d D steps per iteration, the generator steps are not included' % (Bc, dc, hps.n_patch_steps)}
+    del tr, s2
+    torch.cuda.empty_cache()
+    return out
+
+
+def parity_record(enc, dec, dev, B=256):
+    """The benchmarked bf16 model against the fp32 HIP path on the SAME weights, batch and Gumbel noise (eval mode: dropout off),
+    SURVEY 8(d)'s secondary metrics: MBV bit-mismatch rate, relative error of the encoder logits and of x_dec (decoder error
+    alone: both decoders fed the fp32 path's bits; and end to end, bit flips included).  Relative = max|d| / max|ref|."""
+    from zs_amd.model import Decoder, Encoder
+    seg_len, F, E, ch, nspk = 128, 513, enc.enc_size, dec.c_h, dec.c_a
+    g = torch.Generator().manual_seed(4242)
+    x = (torch.rand(B, F, seg_len, generator=g) * (1 - 1e-8) + 1e-8).to(dev)
+    c = torch.randint(0, nspk, (B,), generator=g).to(dev)
+    U = torch.rand(B, seg_len // 8, E, 2, generator=g).to(dev)
+    G = -torch.log(-torch.log(U + 1e-20) + 1e-20)
+    enc32 = Encoder(ns=enc.ns, dp=0.5, enc_size=E, seg_len=seg_len, enc_mode='multilabel_binary', dtype='fp32').to(dev)
+    dec32 = Decoder(ns=dec.ns, c_in=E, c_h=ch, c_a=nspk, seg_len=seg_len, dtype='fp32').to(dev)
+    enc32.load_state_dict(enc.state_dict()); dec32.load_state_dict(dec.state_dict())
+    was = enc.training, dec.training
+    for m in (enc, dec, enc32, dec32):
+        m.eval()
+    with torch.no_grad():
+        act_b, log_b = enc(x, G=G)
+        act_b, log_b = act_b.clone(), log_b.clone()
+        xd_b = dec(act_b, c).clone()
+        act_f, log_f = enc32(x, G=G)
+        xd_f = dec32(act_f, c)
+        xd_b_same = dec(act_f.clone(), c)
+    rel = lambda a, r: float((a.float() - r.float()).abs().max() / r.float().abs().max())
+    out = {'mbv_bit_mismatch_rate': float((act_b != act_f).float().mean()), 'mbv_bits_compared': int(act_f.numel()),
+           'enc_logits_rel_err': rel(log_b, log_f), 'x_dec_rel_err': rel(xd_b_same, xd_f), 'x_dec_rel_err_end_to_end': rel(xd_b, xd_f),
+           'x_dec_mean_abs_err': float((xd_b_same - xd_f).abs().mean()),
+           'reference': 'fp32 HIP path (exact-fp32 MFMA; parity-tested against the oracle at 1e-3), same weights / batch of %d / Gumbel noise, eval mode' % B}
+    enc.train(was[0]); dec.train(was[1])
+    del enc32, dec32
+    torch.cuda.empty_cache()
+    return out
+
+
+GL_TRAFFIC_FILE = 'r02_resynth_pmc_traffic.json'
 
 _JSON_FD = None
 
@@ -502,6 +639,21 @@ def main():
         if B != 16:
             big = cpu_baseline(seg_len, F, E, ch, nspk, steps=1, batch=B)              # and the GPU configuration's
             out['cpu_baseline']['at_gpu_batch'] = {k: big[k] for k in ('value', 'unit', 'sample')}
+    if world == 1 and not parallel.multi_rank() and not args.no_secondary and args.dtype == 'bf16':
+        # secondary records, all outside the timed region: parity of the benchmarked bf16 model, BASELINE configs 4 and 5
+        ke.uninstall()
+        sec = {}
+        sec['parity_bf16_vs_fp32'] = parity_record(enc, dec, dev, B=B)
+        log('secondary: parity %s' % json.dumps(sec['parity_bf16_vs_fp32']))
+        out['mbv_bit_mismatch_rate'] = sec['parity_bf16_vs_fp32']['mbv_bit_mismatch_rate']
+        out['x_dec_rel_err'] = sec['parity_bf16_vs_fp32']['x_dec_rel_err']
+        del ae, enc, dec
+        torch.cuda.empty_cache()
+        sec['resynth'] = resynth_record(args, 0, 1, dev, steps=3, warmup=1, cpu=not args.no_cpu_baseline)
+        log('secondary: config 4 %.0f utterances/s' % sec['resynth']['value'])
+        sec['stage2'] = stage2_record(args, dev, iters=2, cpu=not args.no_cpu_baseline)
+        log('secondary: config 5 %.1f ms per iteration' % sec['stage2']['ms_per_iteration'])
+        out['secondary'] = sec
     emit_json(out)
     if dist.is_initialized():
         dist.barrier()

@@ -43,7 +43,7 @@ const char* zs_last_error(void);
  *   "gemm_ring" (ZS_GEMM_RING, 1): allow the 256x128 3-stage-ring kernel
  *   "gemm_ring_min_tiles" (ZS_GEMM_RING_MIN_TILES, 256): use it when the problem has at least that many 256x128 tiles
  *   "gemm_pp" (ZS_GEMM_PP, 1): ping-pong schedule of the ring kernel (two wave groups one barrier apart)
- *   "gemm_p8" (ZS_GEMM_P8, 2: 16x16x32 MFMA tiles; 1: 32x32x16) / "gemm_p8_min_tiles" (ZS_GEMM_P8_MIN_TILES, 200): 256x256 quadrant ping-pong kernel when the
+ *   "gemm_p8" (ZS_GEMM_P8, 1) / "gemm_p8_min_tiles" (ZS_GEMM_P8_MIN_TILES, 200): 256x256 quadrant ping-pong kernel when the
  *       packed weight has a multiple of 256 rows and the problem has at least that many 256x256 tiles
  *   "wgrad_p8" (ZS_WGRAD_P8, 1): 256x256 ping-pong weight-gradient kernel (bf16) where its heuristics accept the shape;
  *       0 = always the 128x128 kernel, 2 = whenever bf16 (tests)

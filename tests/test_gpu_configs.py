@@ -124,13 +124,12 @@ def test_config2_b256_bf16_default_dispatch_spot_checks(dev):
         got.append(float(o_r[m, ci])); ref.append(float(prod.sum())); absref.append(float(prod.abs().sum()))
     _check('dense2 data gradient (p8m16)', got, ref, absref, True)
 
-    # ---- (4) gemm_wgrad_p8: dense5.weight [1024, 3072] = dz5^T cat[out, rnn, emb5 x T] over M = 32768 rows (with ZS_FOLD_EMB5=1 the
-    #          third column block is a per-speaker bias: its gradient then comes from bf16-rounded per-sample column sums)
+    # ---- (4) gemm_wgrad_p8: dense5.weight [1024, 3072] = dz5^T cat[out, rnn, emb5 x T] over M = 32768 rows
     dz5 = de.ctx.act('d_dz5' + tag, B, T, ch)
     cat3 = tp['cat3']
     gw = dec.grad_view('dense5.weight')
     ncol = cat3.C
-    assert ncol == (2 if de.fold5 else 3) * ch
+    assert ncol == 3 * ch
     cos, cis = rng.randint(ch, size=n_chk), rng.randint(ncol, size=n_chk)
     ycols = _rows(dz5)[:, torch.from_numpy(cos).to(dev)].double().cpu()          # [M, n_chk]
     xcols = _rows(cat3)[:, torch.from_numpy(cis).to(dev)].double().cpu()
@@ -140,14 +139,6 @@ def test_config2_b256_bf16_default_dispatch_spot_checks(dev):
     gb = dec.grad_view('dense5.bias')
     yb_ = _rows(dz5)[:, :ch].double().cpu()
     _check('dense5.bias gradient', gb.double().cpu().numpy(), yb_.sum(0).numpy(), yb_.abs().sum(0).numpy(), False)
-    if de.fold5:
-        s_b = _bf(_rows(dz5)[:, :ch].float().view(B, T, ch).sum(1)).cpu()        # [B, ch] per-sample column sums, as the kernel rounds them
-        e5 = _bf(dec.emb5.weight.detach())[c.cpu()].cpu()                        # [B, ch]
-        cos, cis = rng.randint(ch, size=n_chk), rng.randint(ch, size=n_chk)
-        terms = s_b[:, cos] * e5[:, cis]
-        got = gw[torch.from_numpy(cos), torch.from_numpy(2 * ch + cis)].double().cpu().numpy()
-        ref, aref = terms.sum(0).numpy(), terms.abs().sum(0).numpy()
-        assert (np.abs(got - ref) <= (2.0 ** -8) * aref + 1e-12).all(), 'dense5.weight[:, 2ch:] (folded emb5 block)'
 
     # ---- (5) gemm_wgrad_p8 with taps + reflect + split2 packing: conv5.weight [2048, 1024, 3]
     dza = de.ctx.act('d_dza2' + tag, B, Ti, 2 * ch)
@@ -511,6 +502,94 @@ def test_config3_two_ranks_on_one_gpu_gloo(dev, tmp_path):
     assert len(set(res['losses'])) == len(res['losses'])
 
 
+# ---- config 3 over RCCL: the multi-rank step (four hipGraphs, all-reduces between them) on ONE rank ------------------------
+
+_RCCL_SCRIPT = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r)
+import torch
+import zs_amd
+from zs_amd import parallel, layers
+from zs_amd.model import Decoder, Encoder
+from zs_amd.trainer import AEStep
+import torch.distributed as dist
+
+rank, world, local = parallel.init_from_env('nccl')         # WORLD_SIZE=1 + ZS_FORCE_MULTI=1: a real RCCL communicator of one rank
+assert dist.is_initialized() and dist.get_backend() == 'nccl' and parallel.multi_rank()
+dev = torch.device('cuda', local)
+res = []
+for mode in ('rccl4', 'single'):
+    os.environ['ZS_FORCE_MULTI'] = '1' if mode == 'rccl4' else '0'
+    assert parallel.multi_rank() == (mode == 'rccl4')
+    torch.manual_seed(3)
+    enc = Encoder(c_in=80, c_h1=16, c_h2=64, c_h3=32, ns=0.01, dp=0.5, enc_size=32, seg_len=128, enc_mode='multilabel_binary', dtype='bf16').to(dev)
+    dec = Decoder(c_in=32, c_out=80, c_h=64, c_a=4, ns=0.01, seg_len=128, dtype='bf16').to(dev)
+    if mode == 'rccl4':
+        parallel.broadcast_params([enc, dec])                 # (world 1: returns at once; bench.py broadcasts under multi_rank())
+        for net in (enc, dec):
+            dist.broadcast(net.flat_params()[0], src=0)
+            net.mark_dirty()
+    ae = AEStep(enc, dec, lr=1e-3, max_grad_norm=5.0, use_graph=True)
+    gg = torch.Generator().manual_seed(11)
+    losses = []
+    for i in range(6 + ae.graph_warmup):
+        x = torch.rand(8, 128, 80, generator=gg).to(dev)
+        c = torch.randint(0, 4, (8,), generator=gg).to(dev)
+        losses.append(ae.step(x, c).item())
+    layers.check_status(dev)
+    res.append((losses, enc.flat_params()[0].clone(), dec.flat_params()[0].clone(), sum(len(v['graphs']) for v in ae._graphs.values())))
+(la, ea, da, na), (lb, eb, db, nb) = res
+assert na == 4 and nb == 1, (na, nb)
+assert la == lb, (la, lb)
+assert torch.equal(ea, eb) and torch.equal(da, db), 'the four-graph step over RCCL differs from the single-rank graph step'
+print('RESULT ' + json.dumps({'losses': la, 'graphs': [na, nb]}), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def test_config3_four_graph_step_over_rccl_one_rank(dev, tmp_path):
+    """The multi-rank product path on the real communication backend: ONE child process (fresh: RCCL is initialised before any
+    other GPU work there), WORLD_SIZE=1 + ZS_FORCE_MULTI=1, backend 'nccl' (= RCCL).  The four-graph step with the two
+    all-reduces issued between the graphs equals the single-rank one-graph step bit for bit over 6 replayed steps (a one-rank
+    all-reduce is the identity and 1/world = 1), dropout and Gumbel noise on."""
+    import subprocess
+    script = str(tmp_path / 'rccl_one_rank.py')
+    open(script, 'w').write(_RCCL_SCRIPT % {'root': ROOT})
+    env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()),
+               ZS_FORCE_MULTI='1', OMP_NUM_THREADS='2')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    pr = subprocess.run([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=420)
+    assert pr.returncode == 0, pr.stdout[-4000:]
+    line = [l for l in pr.stdout.splitlines() if l.startswith('RESULT ')]
+    assert line, pr.stdout[-2000:]
+    res = json.loads(line[0][7:])
+    assert res['graphs'] == [4, 1] and len(set(res['losses'])) == len(res['losses'])
+
+
+def test_bench_json_line_is_clean_over_rccl(dev):
+    """bench.py under the multi-rank code path on RCCL (one rank, ZS_FORCE_MULTI=1): stdout carries exactly ONE line and it is
+    the JSON record (RCCL prints a banner on its first collective; bench.claim_stdout keeps it off stdout), four graph segments."""
+    import subprocess
+    env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()),
+               ZS_FORCE_MULTI='1', OMP_NUM_THREADS='2')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--batch', '32',
+                         '--no-cpu-baseline', '--no-secondary'], env=env, capture_output=True, text=True, timeout=420)
+    assert pr.returncode == 0, pr.stderr[-4000:]
+    lines = [l for l in pr.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, pr.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 1 and rec['graph_segments'] == 4 and rec['hipgraph'] is True and rec['value'] > 0
+
+
 def test_host_fed_step_equals_resident_step(dev):
     """trainer.HostFedStep (H2D copy of the next batch as a branch of the captured step, SURVEY 8a row a2): distinct host batches,
     no host synchronisation between steps -- the loss trajectory and the parameters equal those of the same batches fed from
@@ -551,87 +630,6 @@ def test_host_fed_step_equals_resident_step(dev):
         res.append((final, enc.flat_params()[0].clone(), dec.flat_params()[0].clone()))
     assert res[0][0] == res[1][0], (res[0][0], res[1][0])
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
-
-
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
-def test_micro_batch_lanes_equal_the_single_chain(dev, dtype):
-    """ZS_LANES = 2: the batch runs as two concurrent half-batch chains (own streams, buffers, tapes; the second lane accumulates
-    into the first one's parameter gradients).  With injected Gumbel noise and dropout masks the loss and every parameter
-    gradient equal the single-chain step up to the summation order of the weight gradients (fp32: 2e-5 of each tensor's scale;
-    bf16 operands are identical, so the same bound holds), and the hipGraph replay of the two-lane step is deterministic."""
-    import zs_oracle as O
-    from zs_amd.model import Decoder, Encoder
-    from zs_amd.trainer import AEStep
-    B, T, F_, E = 8, 128, 80, 32
-    g = torch.Generator().manual_seed(5)
-    x = torch.rand(B, T, F_, generator=g).to(dev)
-    c = torch.randint(0, 4, (B,), generator=g).to(dev)
-    G = O.gumbel_from_uniform(torch.rand(B, T // 8, E, 2, generator=g)).contiguous().to(dev)
-    masks = [(torch.rand(B, t, 64, generator=g) >= 0.5).to(torch.uint8).to(dev) for t in (T, T // 2, T // 4, T // 8, T // 8, T // 8)]
-    res = []
-    for lanes in (1, 2):
-        torch.manual_seed(0)
-        enc = Encoder(c_in=F_, c_h1=16, c_h2=64, c_h3=32, ns=0.01, dp=0.5, enc_size=E, seg_len=128, enc_mode='multilabel_binary', dtype=dtype).to(dev)
-        dec = Decoder(c_in=E, c_out=F_, c_h=64, c_a=4, ns=0.01, seg_len=128, dtype=dtype).to(dev)
-        ae = AEStep(enc, dec, lr=1e-3, max_grad_norm=5.0, use_graph=False)
-        ae.lanes = lanes
-        loss = ae.step(x, c, noise=G, noise_kind=0, drop_masks=masks, update=False).item()
-        torch.cuda.synchronize()
-        res.append((loss, enc.flat_params()[1].clone(), dec.flat_params()[1].clone(), {k: enc.grad_view(k).clone() for k, _ in enc.named_parameters()},
-                    {k: dec.grad_view(k).clone() for k, _ in dec.named_parameters()}))
-    assert abs(res[0][0] - res[1][0]) < 2e-6, (res[0][0], res[1][0])
-    for which in (3, 4):
-        for k, ref in res[0][which].items():
-            scale = ref.abs().max().item()
-            if scale < 1e-7:
-                continue
-            e = (res[1][which][k] - ref).abs().max().item() / scale
-            assert e < 2e-5, (k, e)
-    # graph replay of the two-lane step: two runs from the same state are bit-identical, the loss falls
-    runs = []
-    for _ in range(2):
-        torch.manual_seed(0)
-        enc = Encoder(c_in=F_, c_h1=16, c_h2=64, c_h3=32, ns=0.01, dp=0.5, enc_size=E, seg_len=128, enc_mode='multilabel_binary', dtype=dtype).to(dev)
-        dec = Decoder(c_in=E, c_out=F_, c_h=64, c_a=4, ns=0.01, seg_len=128, dtype=dtype).to(dev)
-        ae = AEStep(enc, dec, lr=1e-3, max_grad_norm=5.0, use_graph=True)
-        ae.lanes = 2
-        losses = [ae.step(x, c).item() for _ in range(8)]
-        runs.append((losses, enc.flat_params()[0].clone(), dec.flat_params()[0].clone(), sum(len(v['graphs']) for v in ae._graphs.values())))
-    assert runs[0][3] == 1 and runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
-    assert runs[0][0][-1] < runs[0][0][0]
-
-
-def test_folded_emb5_block_equals_the_literal_concatenation(dev, monkeypatch):
-    """ZS_FOLD_EMB5=1 (the third K block of the decoder's dense5 as a per-speaker bias) against the default
-    cat[out, rnn, emb5 x T] GEMM: output and every decoder gradient agree (fp32: 2e-5 of scale)."""
-    from zs_amd.model import Decoder
-    g = torch.Generator().manual_seed(9)
-    bits = (torch.rand(3, 8, 16, generator=g) > 0.5).float()
-    cidx = torch.randint(0, 4, (3,), generator=g)
-    dl = torch.randn(3, 128, 80, generator=g) * 1e-3
-    res = []
-    for fold in ('0', '1'):
-        monkeypatch.setenv('ZS_FOLD_EMB5', fold)
-        torch.manual_seed(1)
-        dec = Decoder(c_in=8, c_out=80, c_h=64, c_a=4, ns=0.01, seg_len=128, dtype='fp32').to(dev)
-        dec.train()
-        eng = dec._engine()
-        assert eng.fold5 == (fold == '1')
-        xd = dec(bits.to(dev), cidx.to(dev))
-        from zs_amd import _lib as L
-        dlog = eng.ctx.act('t_dl', 3, 128, 80)
-        L.call('zs_cast_rows', 'ZsCastRows', eng.ctx.stream, dtype=eng.ctx.dt, src=L.ptr(dl.to(dev).contiguous()), ld_src=80, src_f32=1,
-               dst=dlog.ptr(), ld_dst=dlog.ld, dst_f32=0, col_off=0, rows=3 * 128, cols=80, fill_cols=dlog.ld, act=L.ZS_ACT_NONE)
-        eng.backward(dlog)
-        from zs_amd.layers import join_side
-        join_side(dev)
-        torch.cuda.synchronize()
-        res.append((xd.clone(), {k: dec.grad_view(k).clone() for k, _ in dec.named_parameters()}))
-    assert (res[0][0] - res[1][0]).abs().max().item() < 2e-5
-    for k, ref in res[0][1].items():
-        scale = ref.abs().max().item()
-        if scale > 1e-8:
-            assert (res[1][1][k] - ref).abs().max().item() / scale < 2e-5, k
 
 
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])

@@ -76,7 +76,7 @@ def _ref_conv(x_btc, w, b, stride, reflect):
 
 
 GEMM_KEYS = ('gemm_dma', 'gemm_ring', 'gemm_ring_min_tiles', 'gemm_pp', 'gemm_p8', 'gemm_p8_min_tiles', 'wgrad_p8')
-GEMM_VARIANTS = {'p8': (1, 1, 1, 1, 1, 1, 2), 'p8m16': (1, 1, 1, 1, 2, 1, 0), 'pp': (1, 1, 1, 1, 0, 200, 0), 'ring': (1, 1, 1, 0, 0, 200, 0),
+GEMM_VARIANTS = {'p8m16': (1, 1, 1, 1, 1, 1, 2), 'pp': (1, 1, 1, 1, 0, 200, 0), 'ring': (1, 1, 1, 0, 0, 200, 0),
                  'dma': (1, 0, 256, 0, 0, 200, 0), 'reg': (0, 0, 256, 0, 0, 200, 0)}
 
 
@@ -84,7 +84,7 @@ GEMM_VARIANTS = {'p8': (1, 1, 1, 1, 1, 1, 2), 'p8m16': (1, 1, 1, 1, 2, 1, 0), 'p
 def gemm_variant(request, zs):
     """Run a test with each conv-GEMM kernel: 256x256 quadrant ping-pong (where the packed weight has a multiple of 256 rows,
     else it falls through to the ring), 256x128 3-stage ring with the ping-pong schedule, the same ring in lock-step,
-    128x128 LDS-DMA, 128x128 register-staged.  The 'p8' variant also forces the 256x256 ping-pong weight-gradient kernel
+    128x128 LDS-DMA, 128x128 register-staged.  The 'p8m16' variant also forces the 256x256 ping-pong weight-gradient kernel
     (bf16; wgrad_p8=2 overrides its size heuristics), the others use the 128x128 one."""
     L, _ = zs
     old = [L.set_option(k, v) for k, v in zip(GEMM_KEYS, GEMM_VARIANTS[request.param])]

@@ -209,3 +209,145 @@ def test_main_train_p_synthetic(dev, tmp_path, monkeypatch, capsys):
     out = capsys.readouterr().out
     assert 'patch_G:[000001/000001]' in out and 'pre_AE' not in out
     assert os.path.exists(str(tmp_path / 'ck' / 'model.pth-s2-1'))
+
+
+# ---- BASELINE config 5 at its own size: B = 128, bf16, english hps with enc_size = emb_size = 1024 ---------------------------
+
+def _keep_masks(B, dp, gen):
+    return [(torch.rand(B, C, generator=gen) >= dp).float() for C in (64, 128, 256, 512, 512, 32)]
+
+
+def _refl(u, n):
+    u = np.where(u < 0, -u, u)
+    return np.where(u >= n, 2 * (n - 1) - u, u)
+
+
+def test_config5_b128_bf16_steps_vs_fp32_path_and_fp64_spot_checks(dev, tmp_path):
+    """BASELINE config 5 on one GPU as `tools/stage2_bench.py --tgat` / bench.py's secondary record run it (B = 128, bf16,
+    enc_size = emb_size = 1024; reference trainer.py:467-560, utils.py:58-77): D step, G step and target-guided step are
+    finite and bit-identical when replayed from the same state; w_dis / gp / CE and every discriminator gradient (second-order
+    penalty term included) stay within a stated bound of the fp32 HIP path on the same weights, masks, alpha and x_gen; and,
+    on the operands the bf16 kernels really read, fp64 dot products taken on the host confirm (1) a conv2d_gather + GEMM forward
+    (conv3) and (2) entries of conv3's accumulated weight gradient = real + fake + adjoint-pass + reverse-sweep contributions.
+
+    Bounds (measured values in the test output): |w_dis - fp32| <= 0.02 (|.| + 1), |gp - fp32| <= 0.05 (gp + 1), CE 0.02;
+    gradient tensors: relative L2 error <= 0.08 of the fp32 tensor (bf16 activations through 6 layers and a double backward)."""
+    from zs_amd import layers
+    from zs_amd.hps import make_hps
+    from zs_amd.patch import PatchDiscriminator
+    from zs_amd.stage2 import PatchGANStep
+    from zs_amd.trainer import Trainer
+    torch.manual_seed(0)
+    B = 128
+    hps = make_hps(enc_size=1024, emb_size=1024, batch_size=B)
+    tr = Trainer(hps, None, hps.g_mode, hps.enc_mode, log_dir=str(tmp_path / 'log'), dtype='bf16', device=dev)
+    s2 = tr.stage2()
+    D = tr.PatchDiscriminator
+    g = torch.Generator().manual_seed(0)
+    x_s, x_t = torch.rand(B, 128, 513, generator=g).to(dev), torch.rand(B, 128, 513, generator=g).to(dev)
+    c_t = torch.randint(hps.n_speakers - hps.n_target_speakers, hps.n_speakers, (B,), generator=g).to(dev)
+    masks = [[m.to(dev) for m in _keep_masks(B, D.dp, g)] for _ in range(3)]
+    alpha = torch.rand(B, generator=g).to(dev)
+    x_gen = s2.gen_forward(x_s, c_t, False, seed=77).clone()
+    assert torch.isfinite(x_gen).all()
+
+    def d_once(step):
+        r = step.d_step(None, x_t, c_t, alpha=alpha, masks=masks, update=False, x_gen=x_gen)
+        torch.cuda.synchronize()
+        return (r['w_dis'].item(), r['gp'].item(), r['real_loss_clf'].item()), step.D.flat_params()[1].clone()
+
+    v1, g1 = d_once(s2)
+    v2, g2 = d_once(s2)
+    layers.check_status(dev)
+    assert all(np.isfinite(v1)) and torch.isfinite(g1).all()
+    assert v1 == v2 and torch.equal(g1, g2), 'the bf16 D step is not deterministic'
+
+    # ---- fp64 spot checks on the tapes of that step (before anything overwrites them) ----------------------------------------
+    eng = D._engine()
+    rng = np.random.RandomState(1)
+    ns = float(D.ns)
+    bf = lambda t: t.float().to(torch.bfloat16).double()
+    rows = lambda a: a.t[a.off:a.off + a.rows * a.ld].view(a.rows, a.ld)
+    Wc = D.conv3.weight.detach()                                   # [256, 128, kf = 5, kt = 5]
+    Cout, C, KF, KT = Wc.shape
+    W64 = bf(Wc).cpu()
+    b64 = D.conv3.bias.detach().double().cpu()
+    tp = eng.tapes['real']
+    L1, L2 = tp['layers'][1], tp['layers'][2]
+    H, Wd, Ho, Wo = L2['H'], L2['W'], L2['Ho'], L2['Wo']
+    assert (H, Wd, Ho, Wo, L2['C'], L2['Cout']) == (32, 129, 16, 65, C, Cout)
+    a1 = rows(L1['a']).view(B, H, Wd, -1)                          # layer-2 output [B, H, W, C] (rows ordered b, h, w)
+    y2 = rows(L2['y']).view(B, Ho, Wo, -1)                         # conv3 + lrelu, before InstanceNorm
+    got, ref, aref = [], [], []
+    for _ in range(96):
+        b, ho, wo, co = rng.randint(B), rng.randint(Ho), rng.randint(Wo), rng.randint(Cout)
+        hs, ws = _refl(2 * ho + np.arange(KT) - 2, H), _refl(2 * wo + np.arange(KF) - 2, Wd)
+        patch = a1[b][torch.from_numpy(hs).to(dev)][:, torch.from_numpy(ws).to(dev), :C].double().cpu()      # [kt, kf, C]
+        prod = patch * W64[co].permute(2, 1, 0)                                                               # W[co, c, kf, kt] -> [kt, kf, c]
+        acc = float(prod.sum()) + float(b64[co])
+        got.append(float(y2[b, ho, wo, co])); ref.append(acc if acc > 0 else ns * acc); aref.append(float(prod.abs().sum()) + abs(float(b64[co])))
+    got, ref, aref = np.array(got), np.array(ref), np.array(aref)
+    tol = 2.0 ** -8 * np.abs(ref) + 2e-4 * aref + 1e-12
+    assert (np.abs(got - ref) <= tol).all(), 'conv3 forward (gather + GEMM): worst |d|/tol %.3g' % (np.abs(got - ref) / tol).max()
+
+    # conv3.weight gradient = sum over the four passes that feed it of dY^T gather_W(xh)
+    name = lambda key, what: eng.ctx.act(eng._name(key, what, B), B, Ho * Wo, Cout)
+    passes = []
+    for key in ('real', 'fake'):
+        passes.append((name(key, 'bgz2'), eng.tapes[key]['layers'][2]['xin']))
+    ti = eng.tapes['inter']['layers'][2]
+    passes.append((ti['gz'], eng.ctx.act(eng._name('inter', 'gxh2', B), B * Ho, Wd, 5 * C, ld=ti['layer'].cin_pad)))
+    passes.append((name('inter', 'rgz2'), ti['xin']))
+    gW = D.grad_view('conv3.weight')
+    got, ref, aref = [], [], []
+    wo_idx = torch.arange(Wo, device=dev)
+    for _ in range(24):
+        co, c, kf, kt = rng.randint(Cout), rng.randint(C), rng.randint(KF), rng.randint(KT)
+        wi = torch.from_numpy(_refl(2 * np.arange(Wo) + kf - 2, Wd)).to(dev)
+        tot, tota = 0.0, 0.0
+        for dY, xh in passes:
+            ycol = rows(dY).view(B * Ho, Wo, -1)[:, :, co].double()                       # [B*Ho, Wo]
+            xcol = rows(xh).view(B * Ho, Wd, -1)[:, wi, kt * C + c].double()               # [B*Ho, Wo]
+            pr = ycol * xcol
+            tot += float(pr.sum()); tota += float(pr.abs().sum())
+        got.append(float(gW[co, c, kf, kt])); ref.append(tot); aref.append(tota)
+    got, ref, aref = np.array(got), np.array(ref), np.array(aref)
+    tol = 2e-4 * aref + 1e-12
+    assert np.abs(ref).max() > 0
+    assert (np.abs(got - ref) <= tol).all(), 'conv3.weight gradient (4 passes, second-order term included): worst |d|/tol %.3g' % (np.abs(got - ref) / tol).max()
+
+    # ---- the same step on the fp32 HIP path: same weights, masks, alpha, x_gen ------------------------------------------------
+    D32 = PatchDiscriminator(n_class=D.n_class, ns=D.ns, dp=D.dp, seg_len=D.seg_len, dtype='fp32').to(dev)
+    D32.load_state_dict(D.state_dict())
+    st32 = PatchGANStep.__new__(PatchGANStep)
+    st32.D, st32.hps, st32.g_mode, st32.shift, st32.device = D32, hps, s2.g_mode, s2.shift, dev
+    st32.loss_clf = torch.zeros(1, device=dev); st32.correct = torch.zeros(1, dtype=torch.int32, device=dev)
+    v32, g32 = d_once(st32)
+    print('B=128 D step: bf16 (w_dis, gp, CE) = %s; fp32 path = %s' % (v1, v32))
+    assert abs(v1[0] - v32[0]) <= 0.02 * (abs(v32[0]) + 1) and abs(v1[1] - v32[1]) <= 0.05 * (v32[1] + 1) and abs(v1[2] - v32[2]) <= 0.02
+    worst = ('', 0.0)
+    for k, p in D.named_parameters():
+        a, r = D.grad_view(k).double(), D32.grad_view(k).double()
+        if k.startswith('conv7') and k.endswith('bias'):
+            continue                                               # d/d(conv7.bias): the critic's bias cancels in w_dis and in gp (exactly 0 +- rounding)
+        e = ((a - r).norm() / r.norm().clamp_min(1e-30)).item()
+        if e > worst[1]:
+            worst = (k, e)
+        assert e <= 0.08, (k, e)
+    print('B=128 D step: worst relative L2 error of a bf16 gradient tensor vs the fp32 path: %s %.3g' % worst)
+    del D32, st32
+    torch.cuda.empty_cache()
+
+    # ---- G step and target-guided step: finite, deterministic ----------------------------------------------------------------
+    G = tr.Generator
+    res = []
+    for _ in range(2):
+        r = s2.g_step(x_s, x_t, c_t, masks=masks[0], update=False, seed=78)
+        ladv = r['loss_adv'].item()
+        gg = G.flat_params()[1].clone()
+        lrec = s2.tg_step(x_t, c_t, update=False, seed=79).item()
+        res.append((ladv, gg, lrec, G.flat_params()[1].clone()))
+    layers.check_status(dev)
+    assert np.isfinite(res[0][0]) and np.isfinite(res[0][2]) and torch.isfinite(res[0][1]).all() and torch.isfinite(res[0][3]).all()
+    assert res[0][0] == res[1][0] and res[0][2] == res[1][2] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][3], res[1][3])
+    assert res[0][1].abs().max().item() > 0 and res[0][3].abs().max().item() > 0

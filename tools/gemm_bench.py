@@ -16,7 +16,7 @@ ap.add_argument('--B', type=int, default=256); ap.add_argument('--T', type=int, 
 ap.add_argument('--cin', type=int, default=1024); ap.add_argument('--cout', type=int, default=2048)
 ap.add_argument('--k', type=int, default=3); ap.add_argument('--dtype', default='bf16')
 ap.add_argument('--iters', type=int, default=20); ap.add_argument('--mode', default='fwd')
-ap.add_argument('--variants', default='p8m16,p8,dma')
+ap.add_argument('--variants', default='p8m16,ring,dma')
 ap.add_argument('--rounds', type=int, default=5)
 ap.add_argument('--fill', default='normal', help='normal | zeros | ones: operand values (MFMA power depends on bit toggling)')
 a = ap.parse_args()
@@ -71,7 +71,7 @@ def timed():
 
 
 fl = 2.0 * a.B * a.T * a.cout * a.cin * a.k
-VARIANTS = {'p8': (1, 1, 1, 1, 1, 1), 'p8m16': (1, 1, 1, 1, 2, 1), 'pp': (1, 1, 1, 1, 0, 200), 'ring': (1, 1, 1, 0, 0, 200), 'dma': (1, 0, 256, 0, 0, 200), 'reg': (0, 0, 256, 0, 0, 200)}
+VARIANTS = {'p8m16': (1, 1, 1, 1, 1, 1), 'pp': (1, 1, 1, 1, 0, 200), 'ring': (1, 1, 1, 0, 0, 200), 'dma': (1, 0, 256, 0, 0, 200), 'reg': (0, 0, 256, 0, 0, 200)}
 names = a.variants.split(',') if a.mode != 'wgrad' else ['p8', 't128']
 
 

@@ -288,15 +288,6 @@ def encode_batch(specs, trainer, seg_len, decode_speakers=None, noise_fn=None, m
     main = torch.cuda.current_stream(dev)
     streams = [main] + [layers.lane_stream(dev, 100 + i) for i in range(1, n_streams)]
     ctxs = [enc._engine().ctx, dec._engine().ctx]
-    # ZS_INFER_GRAPH=1: replay a cached hipGraph per (stream, batch, length).  Off by default: measured SLOWER (151 vs 131 ms per
-    # 64-utterance batch) -- on this stack a graph launch does not run beside work on other streams, so the length groups'
-    # GRU recurrences serialise again and that costs more than the ~4000 Python launches save.
-    graphs = _infer_graphs(trainer) if os.environ.get('ZS_INFER_GRAPH', '0') == '1' else None
-    # ZS_INFER_PLAN=1: re-issue recorded launch lists instead (real streams, ~1.5 us of host time per launch): measured equal to
-    # the plain path (120 ms per batch either way: the groups are bound by their GRU recurrences and the host-side copies, not by
-    # the Python launches), so it is off by default as well
-    if graphs is None and os.environ.get('ZS_INFER_PLAN', '0') == '1':
-        graphs = _infer_graphs(trainer, InferPlans)
     groups = sorted(by_len.items(), key=lambda kv: -len(kv[1]))
     ev0 = torch.cuda.Event()
     gi = 0
@@ -315,10 +306,6 @@ def encode_batch(specs, trainer, seg_len, decode_speakers=None, noise_fn=None, m
                 with torch.cuda.stream(streams[k]):
                     xh = torch.from_numpy(np.stack([padded[u][a:b] for (u, _, a, b, _) in chunk]))                  # [n, Tf, 513]
                     ch = torch.tensor([decode_speakers[u] for (u, _, _, _, _) in chunk], dtype=torch.int64) if decode_speakers is not None else None
-                    if noise_fn is None and graphs is not None:
-                        e_dev, xd = graphs.run(k, streams[k], xh, ch)
-                        pending.append((chunk, e_dev, xd))
-                        continue
                     x = xh.to(dev, non_blocking=True)
                     G = noise_fn(len(chunk), ((((Tf + 1) // 2 + 1) // 2) + 1) // 2, enc.enc_size) if noise_fn is not None else None
                     act, _ = enc(x.permute(0, 2, 1), G=G)
@@ -350,98 +337,6 @@ def encode_batch(specs, trainer, seg_len, decode_speakers=None, noise_fn=None, m
             parts = [dec_out[(u, k)] for k in ks]
             decs.append(np.concatenate(parts, axis=0) if to_host else (parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)))
     return encs, decs
-
-
-class InferGraphs(object):
-    """hipGraph cache of the eval-mode Encoder (+ Decoder) forward per (stream lane, batch, fragment length): the fragment rule
-    makes inference a long tail of small batches whose cost is ~120 Python-issued launches each; the second time a shape is seen
-    its launches are captured, afterwards they are replayed (one call) with the input copied into the graph's static buffer and the
-    Gumbel noise seed advanced on the device (the reference draws fresh noise at every eval forward, model/model.py:95-98)."""
-
-    def __init__(self, trainer, max_entries=2048):
-        self.tr, self.dev = trainer, trainer.device
-        self.seen, self.graphs, self.max_entries = set(), {}, max_entries
-        self.seeds = {}
-        self.nonce = 0
-
-    def _seed(self, k):
-        if k not in self.seeds:
-            s0 = int(torch.randint(0, 2 ** 62, (1,)).item())
-            self.seeds[k] = torch.tensor([s0], dtype=torch.int64, device=self.dev)
-        return self.seeds[k]
-
-    def _forward(self, x_dev, c_dev, seed_ptr):
-        enc, dec = self.tr.Encoder, self.tr.Decoder
-        ee, de = enc._engine(), dec._engine()
-        bits, bits_f32, _ = ee.forward(x_dev, False, noise=None, noise_kind=2, seed=0, seed_ptr=seed_ptr)
-        xdec = de.forward(bits, c_dev, False) if c_dev is not None else None
-        return bits_f32, xdec
-
-    def run(self, k, stream, x_host, c_host):
-        """x_host: CPU fp32 [n, Tf, 513]; c_host: CPU int64 [n] or None.  Returns (enc_act [n, T', E], x_dec [n, T_out, 513] or None)
-        as fresh device tensors.  Must be called with `stream` current and the engines' lane set."""
-        n, Tf = x_host.shape[0], x_host.shape[1]
-        key = (k, n, Tf, c_host is not None)
-        seed = self._seed(k)
-        L.check(L.lib().zs_step_counters(L.ptr(seed), None, stream.cuda_stream), 'zs_step_counters')
-        ent = self.graphs.get(key)
-        if ent is None:
-            x_dev = x_host.to(self.dev, non_blocking=True)
-            c_dev = c_host.to(self.dev, non_blocking=True) if c_host is not None else None
-            if key not in self.seen or len(self.graphs) >= self.max_entries:
-                self.seen.add(key)                                   # first sighting: eager (this also allocates the buffers)
-                bits_f32, xdec = self._forward(x_dev, c_dev, L.ptr(seed))
-                return bits_f32.clone(), (xdec.valid().contiguous() if xdec is not None else None)
-            g = torch.cuda.CUDAGraph()
-            xs, cs = x_dev.clone(), (c_dev.clone() if c_dev is not None else None)
-            stream.synchronize()
-            with torch.cuda.graph(g, capture_error_mode='thread_local'):        # (captured on torch's side stream; replayed on ours)
-                bits_f32, xdec = self._forward(xs, cs, L.ptr(seed))
-            ent = self.graphs[key] = {'g': g, 'x': xs, 'c': cs, 'bits': bits_f32, 'xdec': xdec}
-        else:
-            ent['x'].copy_(x_host, non_blocking=True)
-            if c_host is not None:
-                ent['c'].copy_(c_host, non_blocking=True)
-        ent['g'].replay()
-        return ent['bits'].clone(), (ent['xdec'].valid().contiguous() if ent['xdec'] is not None else None)
-
-
-class InferPlans(InferGraphs):
-    """The same cache with launch LISTS instead of hipGraphs: the first time a (stream, batch, length) group is seen its ~120
-    kernel calls are recorded while they run (_lib.record), afterwards they are re-issued from the list (no argument marshalling:
-    ~1.5 us instead of ~15 us of Python per launch) on real streams -- unlike graph launches these DO run beside each other."""
-
-    def run(self, k, stream, x_host, c_host):
-        n, Tf = x_host.shape[0], x_host.shape[1]
-        key = (k, n, Tf, c_host is not None)
-        seed = self._seed(k)
-        L.check(L.lib().zs_step_counters(L.ptr(seed), None, stream.cuda_stream), 'zs_step_counters')
-        ent = self.graphs.get(key)
-        if ent is None:
-            xs = x_host.to(self.dev, non_blocking=True)
-            cs = c_host.to(self.dev, non_blocking=True) if c_host is not None else None
-            with L.record() as rec:
-                bits_f32, xdec = self._forward(xs, cs, L.ptr(seed))
-            if len(self.graphs) < self.max_entries and not getattr(self, '_unplannable', False):
-                self.graphs[key] = {'calls': rec.calls, 'x': xs, 'c': cs, 'bits': bits_f32, 'xdec': xdec}
-        else:
-            ent['x'].copy_(x_host, non_blocking=True)
-            if c_host is not None:
-                ent['c'].copy_(c_host, non_blocking=True)
-            L.replay(ent['calls'], stream.cuda_stream)
-            bits_f32, xdec = ent['bits'], ent['xdec']
-        return bits_f32.clone(), (xdec.valid().contiguous() if xdec is not None else None)
-
-
-def _infer_graphs(trainer, cls=None):
-    """The trainer's graph / plan cache; dropped when an engine was rebuilt (new device / dtype: the entries point into its buffers)."""
-    cls = cls or InferGraphs
-    ids = (id(trainer.Encoder._engine()), id(trainer.Decoder._engine()), cls.__name__)
-    g = getattr(trainer, '_infer_graphs', None)
-    if g is None or g.ids != ids:
-        g = trainer._infer_graphs = cls(trainer)
-        g.ids = ids
-    return g
 
 
 def write_wav(path, wav, sr):

@@ -802,208 +802,14 @@ constexpr int P8_EPI = 256 * CPITCH * 4;                      // 135,168 B: stag
 constexpr int P8_LDS = (2 * PSTAGE > P8_EPI) ? 2 * PSTAGE : P8_EPI;
 
 #define ZS_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
-#define ZS_P8_READ_A(o0, o1)                                                     \
-  ZS_DSR(fa00, sa + koff0, o0); ZS_DSR(fa01, sa + koff0, o1); ZS_DSR(fa10, sa + koff1, o0); ZS_DSR(fa11, sa + koff1, o1); \
-  ZS_DSR(fa20, sa + koff2, o0); ZS_DSR(fa21, sa + koff2, o1); ZS_DSR(fa30, sa + koff3, o0); ZS_DSR(fa31, sa + koff3, o1);
-#define ZS_P8_READ_B(f0, f1, f2, f3, o)                                          \
-  ZS_DSR(f0, sb + koff0, o); ZS_DSR(f1, sb + koff1, o); ZS_DSR(f2, sb + koff2, o); ZS_DSR(f3, sb + koff3, o);
-#define ZS_P8_MMA(a, b, c) Mma<T>::run(make_uint4(a.x, a.y, a.z, a.w), make_uint4(b.x, b.y, b.z, b.w), c)
 #define ZS_P8_DMA(cond, src, dst)                                                \
   __builtin_amdgcn_sched_barrier(0);                                             \
   if (cond) __builtin_amdgcn_global_load_lds((gptr_t)(src), (lptr_t)(dst), 16, 0, 0); \
   __builtin_amdgcn_sched_barrier(0);
-// one quadrant: 8 MFMAs (k-step major, the two 32-row tiles alternate) with two DMA pieces between them
-#define ZS_P8_QUAD(c0, c1, b0, b1, b2, b3, cond, src0, dst0, src1, dst1)         \
-  __builtin_amdgcn_s_setprio(1);                                                 \
-  ZS_P8_MMA(fa00, b0, c0); ZS_P8_MMA(fa01, b0, c1);                              \
-  ZS_P8_DMA(cond, src0, dst0)                                                    \
-  ZS_P8_MMA(fa10, b1, c0); ZS_P8_MMA(fa11, b1, c1); ZS_P8_MMA(fa20, b2, c0);     \
-  ZS_P8_DMA(cond, src1, dst1)                                                    \
-  ZS_P8_MMA(fa21, b2, c1); ZS_P8_MMA(fa30, b3, c0); ZS_P8_MMA(fa31, b3, c1);     \
-  __builtin_amdgcn_s_setprio(0);
-
-template <typename T>
-__global__ __launch_bounds__(PNT, 2) void gemm_conv_p8_kernel(const ZsGemmConv p) {
-  constexpr int EPS = 16 / (int)sizeof(T);
-  constexpr int KC = ROWB / (int)sizeof(T);
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef __attribute__((address_space(1))) const void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-  const int g = blockIdx.z;
-  const T* __restrict__ A = (const T*)p.A + (int64_t)g * p.a_gstride;
-  const T* __restrict__ W = (const T*)p.W + (int64_t)g * p.w_gstride;
-  const int M = p.B * p.T_out;
-  const int ntn = (p.N + PBN - 1) / PBN;
-  const int ntm = (M + PBM - 1) / PBM;
-  const int wg = xcd_remap(blockIdx.x, ntm * ntn);
-  constexpr int GM = 4;
-  const int per_group = GM * ntn;
-  const int grp = wg / per_group;
-  const int gm = min(GM, ntm - grp * GM);
-  const int in_g = wg - grp * per_group;
-  const int m0 = (grp * GM + in_g % gm) * PBM, n0 = (in_g / gm) * PBN;
-
-  // loader: piece j = 0..3 of a K tile covers rows (j>>1)*128 + wave*16 + (j&1)*8 + lane/8 of A and of W
-  const int lrow = lane >> 3, slot = lane & 7;
-  int rb[4], rt[4], lseg[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int r = (j >> 1) * 128 + wave * 16 + (j & 1) * 8 + lrow;
-    lseg[j] = slot ^ ((r >> 1) & 7);
-    const int m = m0 + r;
-    if (m < M) { rb[j] = m / p.T_out; rt[j] = m - rb[j] * p.T_out; } else { rb[j] = -1; rt[j] = 0; }
-  }
-  const int chunks_per_tap = p.cin_pad / KC;
-  const T* zline = reinterpret_cast<const T*>(zs_zero_line);
-  const T *pa0, *pa1, *pa2, *pa3;
-  int inc0, inc1, inc2, inc3;
-#define ZS_SET_TAP(i, ptr, inc)                                                                         \
-  {                                                                                                     \
-    bool ok = false; int srow = 0;                                                                      \
-    if (rb[i] >= 0) srow = conv_src_row(p.gather, p.pad_mode, p.stride, p.pad_left, p.T_in, rt[i], tap, ok); \
-    ptr = ok ? (A + (int64_t)rb[i] * p.a_batch_stride + (int64_t)srow * p.lda + lseg[i] * EPS) : (zline + lseg[i] * EPS); \
-    inc = ok ? KC : 0;                                                                                  \
-  }
-  const int nk = p.taps * chunks_per_tap;
-  int tap = 0, cit = 0;
-  { ZS_SET_TAP(0, pa0, inc0) ZS_SET_TAP(1, pa1, inc1) ZS_SET_TAP(2, pa2, inc2) ZS_SET_TAP(3, pa3, inc3) }
-  auto advance_a = [&]() {
-    if (++cit == chunks_per_tap) {
-      cit = 0; ++tap;
-      if (tap < p.taps) { ZS_SET_TAP(0, pa0, inc0) ZS_SET_TAP(1, pa1, inc1) ZS_SET_TAP(2, pa2, inc2) ZS_SET_TAP(3, pa3, inc3) }
-    } else {
-      pa0 += inc0; pa1 += inc1; pa2 += inc2; pa3 += inc3;
-    }
-  };
-#undef ZS_SET_TAP
-  // W rows n0 + r_j (the packed matrix has n_pad >= n0 + 256 rows: checked on the host)
-  const T* pw0 = W + (int64_t)(n0 + wave * 16 + lrow) * p.ldw + lseg[0] * EPS;
-  const T* pw1 = W + (int64_t)(n0 + wave * 16 + 8 + lrow) * p.ldw + lseg[1] * EPS;
-  const int64_t whalf = (int64_t)128 * p.ldw;                 // rows +128: pieces 2, 3
-
-  unsigned char* const ldsA = smem + wave * 2048;             // + stage*PSTAGE + (j>>1)*16384 + (j&1)*1024
-  unsigned char* const ldsB = smem + 32768 + wave * 2048;
-
-  f32x16 c000, c001, c010, c011, c100, c101, c110, c111;     // c[mq][nq][mi]
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { c000[r] = 0.f; c001[r] = 0.f; c010[r] = 0.f; c011[r] = 0.f; c100[r] = 0.f; c101[r] = 0.f; c110[r] = 0.f; c111[r] = 0.f; }
-
-  // fragment addresses: A row = wr*128 + mq*64 + mi*32 + (lane&31), W row = wc*64 + nq*32 + (lane&31); slot = (2ks + lane>>5) ^ ((row>>1)&7)
-  const int frow = lane & 31, fh = lane >> 5, fx = (frow >> 1) & 7;
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  const unsigned a_lane = lds0 + (unsigned)((wr * 128 + frow) * 128);
-  const unsigned b_lane = lds0 + (unsigned)(32768 + (wc * 64 + frow) * 128);
-  const unsigned koff0 = (unsigned)(((0 + fh) ^ fx) * 16), koff1 = (unsigned)(((2 + fh) ^ fx) * 16);
-  const unsigned koff2 = (unsigned)(((4 + fh) ^ fx) * 16), koff3 = (unsigned)(((6 + fh) ^ fx) * 16);
-  const int grp1 = wr;
-
-  // prologue: A(0) B(0) -> stage 0, B(1) -> stage 1
-  __builtin_amdgcn_global_load_lds((gptr_t)pa0, (lptr_t)(ldsA), 16, 0, 0);
-  __builtin_amdgcn_global_load_lds((gptr_t)pa1, (lptr_t)(ldsA + 1024), 16, 0, 0);
-  __builtin_amdgcn_global_load_lds((gptr_t)pa2, (lptr_t)(ldsA + 16384), 16, 0, 0);
-  __builtin_amdgcn_global_load_lds((gptr_t)pa3, (lptr_t)(ldsA + 16384 + 1024), 16, 0, 0);
-  advance_a();
-  __builtin_amdgcn_global_load_lds((gptr_t)pw0, (lptr_t)(ldsB), 16, 0, 0);
-  __builtin_amdgcn_global_load_lds((gptr_t)pw1, (lptr_t)(ldsB + 1024), 16, 0, 0);
-  __builtin_amdgcn_global_load_lds((gptr_t)(pw0 + whalf), (lptr_t)(ldsB + 16384), 16, 0, 0);
-  __builtin_amdgcn_global_load_lds((gptr_t)(pw1 + whalf), (lptr_t)(ldsB + 16384 + 1024), 16, 0, 0);
-  pw0 += KC; pw1 += KC;
-  if (nk > 1) {
-    __builtin_amdgcn_global_load_lds((gptr_t)pw0, (lptr_t)(ldsB + PSTAGE), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)pw1, (lptr_t)(ldsB + PSTAGE + 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(pw0 + whalf), (lptr_t)(ldsB + PSTAGE + 16384), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(pw1 + whalf), (lptr_t)(ldsB + PSTAGE + 16384 + 1024), 16, 0, 0);
-    pw0 += KC; pw1 += KC;
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  if (grp1) __builtin_amdgcn_s_barrier();
-
-  u32x4_t fa00, fa01, fa10, fa11, fa20, fa21, fa30, fa31;    // fa[ks][mi]
-  u32x4_t fb00, fb01, fb02, fb03, fb10, fb11, fb12, fb13;    // fb[nq][ks]
-  for (int kt = 0; kt < nk; ++kt) {
-    const int st = kt & 1;
-    const unsigned sa = a_lane + (unsigned)(st * PSTAGE), sb = b_lane + (unsigned)(st * PSTAGE);
-    const bool has_a = kt + 1 < nk, has_b = kt + 2 < nk;
-    unsigned char* const dA = ldsA + (st ^ 1) * PSTAGE;
-    unsigned char* const dB = ldsB + st * PSTAGE;
-    // ---- phase 1: quadrant (0,0); A0(kt+1)
-    ZS_P8_READ_A(0, 4096)
-    ZS_P8_READ_B(fb00, fb01, fb02, fb03, 0)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    ZS_P8_QUAD(c000, c001, fb00, fb01, fb02, fb03, has_a, pa0, dA, pa1, dA + 1024)
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- phase 2: quadrant (0,1); A1(kt+1)
-    ZS_P8_READ_B(fb10, fb11, fb12, fb13, 4096)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    ZS_P8_QUAD(c010, c011, fb10, fb11, fb12, fb13, has_a, pa2, dA + 16384, pa3, dA + 16384 + 1024)
-    if (has_a) advance_a();
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- phase 3: quadrant (1,1); B0(kt+2)
-    ZS_P8_READ_A(8192, 12288)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    ZS_P8_QUAD(c110, c111, fb10, fb11, fb12, fb13, has_b, pw0, dB, pw1, dB + 1024)
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- phase 4: quadrant (1,0); B1(kt+2); the counted waits for tile kt+1
-    if (grp1) {
-      if (has_b) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    ZS_P8_QUAD(c100, c101, fb00, fb01, fb02, fb03, has_b, pw0 + whalf, dB + 16384, pw1 + whalf, dB + 16384 + 1024)
-    if (has_b) { pw0 += KC; pw1 += KC; }
-    if (!grp1) {
-      if (has_b) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (!grp1) __builtin_amdgcn_s_barrier();          // pairs with group 1's last barrier
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  // epilogue in two 128-column halves through the [256][132] fp32 staging tile
-  float* sC = reinterpret_cast<float*>(smem);
-#pragma unroll 1
-  for (int h = 0; h < 2; ++h) {
-    if ((wc >> 1) == h) {
-      const int cb = (wc & 1) * 64 + (lane & 31);
-      const int rbase = wr * 128 + 4 * (lane >> 5);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ro = (r & 3) + 8 * (r >> 2);
-        sC[(rbase + ro) * CPITCH + cb] = c000[r];            sC[(rbase + 32 + ro) * CPITCH + cb] = c001[r];
-        sC[(rbase + ro) * CPITCH + cb + 32] = c010[r];       sC[(rbase + 32 + ro) * CPITCH + cb + 32] = c011[r];
-        sC[(rbase + 64 + ro) * CPITCH + cb] = c100[r];       sC[(rbase + 96 + ro) * CPITCH + cb] = c101[r];
-        sC[(rbase + 64 + ro) * CPITCH + cb + 32] = c110[r];  sC[(rbase + 96 + ro) * CPITCH + cb + 32] = c111[r];
-      }
-    }
-    __syncthreads();
-    epilogue_colsum<PNT>(p, sC, M, m0, n0 + h * 128, tid);
-    epilogue_finish<T, PNT>(p, sC, M, m0, n0 + h * 128, tid, g);
-    __syncthreads();
-  }
-}
-
-// ---- the same kernel on v_mfma_f32_16x16x32_bf16 (fp32: 16x16x4): a pure-MFMA probe (tools/mfma_power.hip) sustains
-// 2.07 PFLOP/s with the 16x16x32 shape against 1.80 PFLOP/s with 32x32x16 on random operands under the 1400 W cap, i.e. the
-// smaller tile is the more energy-efficient instruction.  Same LDS layout, read counts and phases; a quadrant is 4x2 tiles
-// of 16x16 x 2 k-steps of 32 = 16 MFMAs.
+// ---- MFMA shape: v_mfma_f32_16x16x32_bf16 (fp32: 16x16x4).  A pure-MFMA probe (tools/mfma_power.hip) sustains 2.07 PFLOP/s
+// with the 16x16x32 shape against 1.80 PFLOP/s with 32x32x16 on random operands under the 1400 W cap, i.e. the smaller tile is
+// the more energy-efficient instruction (a 32x32x16 twin of this kernel was measured and removed in round 3).  A quadrant is
+// 4x2 tiles of 16x16 x 2 k-steps of 32 = 16 MFMAs.
 typedef __attribute__((ext_vector_type(4))) float f32x4_m;
 template <typename T> struct Mma16;
 template <> struct Mma16<bf16_t> {
@@ -2056,13 +1862,12 @@ WgradPlan wgrad_plan(const ZsGemmWgrad* p) {
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 Knob g_use_dma("ZS_GEMM_DMA", 1), g_use_ring("ZS_GEMM_RING", 1), g_ring_min_tiles("ZS_GEMM_RING_MIN_TILES", 256), g_use_pp("ZS_GEMM_PP", 1),
-    g_use_p8("ZS_GEMM_P8", 2), g_p8_min_tiles("ZS_GEMM_P8_MIN_TILES", 200);
+    g_use_p8("ZS_GEMM_P8", 1), g_p8_min_tiles("ZS_GEMM_P8_MIN_TILES", 200);
 
 // one-time raise of the dynamic-LDS limit of the big-tile kernels (std::call_once: launches may come from several threads)
 std::once_flag g_lds_attr_once;
 void set_lds_attrs() {
-  const void* big[] = {reinterpret_cast<const void*>(gemm_conv_p8_kernel<float>), reinterpret_cast<const void*>(gemm_conv_p8_kernel<bf16_t>),
-                       reinterpret_cast<const void*>(gemm_conv_p8m16_kernel<float>), reinterpret_cast<const void*>(gemm_conv_p8m16_kernel<bf16_t>),
+  const void* big[] = {reinterpret_cast<const void*>(gemm_conv_p8m16_kernel<float>), reinterpret_cast<const void*>(gemm_conv_p8m16_kernel<bf16_t>),
                        reinterpret_cast<const void*>(gemm_wgrad_p8_kernel)};
   for (const void* f : big) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
   const void* ring[] = {reinterpret_cast<const void*>(gemm_conv_ring_kernel<float, 0>), reinterpret_cast<const void*>(gemm_conv_ring_kernel<bf16_t, 0>),
@@ -2113,11 +1918,8 @@ extern "C" int zs_gemm_conv(const ZsGemmConv* p, void* stream) {
   if (use_dma && use_p8 && p->n_pad % PBN == 0 && p8_tiles >= g_p8_min_tiles.get() && p8_tiles < (1ll << 31)) {
     // enough 256x256 tiles for most of the chip: quadrant ping-pong kernel
     dim3 pgrid((unsigned)p8_tiles, 1, (unsigned)groups);
-    if (use_p8 == 2) {
-      if (p->dtype == ZS_F32) hipLaunchKernelGGL(gemm_conv_p8m16_kernel<float>, pgrid, dim3(PNT), P8_LDS, s, *p);
-      else hipLaunchKernelGGL(gemm_conv_p8m16_kernel<bf16_t>, pgrid, dim3(PNT), P8_LDS, s, *p);
-    } else if (p->dtype == ZS_F32) hipLaunchKernelGGL(gemm_conv_p8_kernel<float>, pgrid, dim3(PNT), P8_LDS, s, *p);
-    else hipLaunchKernelGGL(gemm_conv_p8_kernel<bf16_t>, pgrid, dim3(PNT), P8_LDS, s, *p);
+    if (p->dtype == ZS_F32) hipLaunchKernelGGL(gemm_conv_p8m16_kernel<float>, pgrid, dim3(PNT), P8_LDS, s, *p);
+    else hipLaunchKernelGGL(gemm_conv_p8m16_kernel<bf16_t>, pgrid, dim3(PNT), P8_LDS, s, *p);
   } else if (use_dma && use_ring && ring_tiles >= g_ring_min_tiles.get() && ring_tiles < (1ll << 31)) {
     // enough 256x128 tiles to give every CU one workgroup: 3-stage ring kernel
     dim3 rgrid((unsigned)ring_tiles, 1, (unsigned)groups);

@@ -24,21 +24,7 @@ def _half_up(t):
     return (t + 1) // 2
 
 
-class _Taped(object):
-    """`tape` of an engine, one per micro-batch lane of its context (see layers.Ctx.lane)."""
-
-    @property
-    def tape(self):
-        return self._tapes.get(self.ctx.lane)
-
-    @tape.setter
-    def tape(self, tp):
-        if not hasattr(self, '_tapes'):
-            self._tapes = {}
-        self._tapes[self.ctx.lane] = tp
-
-
-class EncoderEngine(_Taped):
+class EncoderEngine(object):
     def __init__(self, ctx, P, G, c_in, c_h1, c_h2, c_h3, enc_size, ns, dp, seg_len):
         """P / G: dicts name -> fp32 parameter / gradient tensors (reference state_dict names)."""
         self.ctx = ctx
@@ -88,7 +74,7 @@ class EncoderEngine(_Taped):
         L.call('zs_cast_rows', 'ZsCastRows', st, dtype=c.dt, src=L.ptr(x), ld_src=F, src_f32=1, dst=xin.ptr(), ld_dst=xin.ld,
                dst_f32=0, col_off=0, rows=B * T, cols=F, fill_cols=xin.ld, act=L.ZS_ACT_NONE,
                dst2=cat.ptr(), ld_dst2=cat.ld, col_off2=7 * c1, fill_cols2=cat.ld - 7 * c1, act2=LRELU, slope2=ns)    # :445-446
-        if c.overlap_wgrad and B * T >= 4096 and not (c.lane and os.environ.get('ZS_LANE_BANK_FORK', '0') != '1'):
+        if c.overlap_wgrad and B * T >= 4096:
             # the seven bank convs are independent and each fills half the chip at most (N = 128): run them side by side
             sts = fork_side(c.device)
             for i, l in enumerate(self.conv1s):                                                               # :441-444
@@ -235,7 +221,7 @@ class EncoderEngine(_Taped):
                dact_ld=(dact.ld if dact is not None else 0), slope=self.ns, out=out.ptr(), ldo=out.ld, unshuffle=0)
 
 
-class DecoderEngine(_Taped):
+class DecoderEngine(object):
     def __init__(self, ctx, P, G, c_in, c_out, c_h, c_a, ns, seg_len, output_mask=False):
         self.ctx = ctx
         self.uid = _uid()
@@ -251,27 +237,12 @@ class DecoderEngine(_Taped):
         self.convs = [(mk('conv%d' % a, split2=True), mk('conv%d' % b)) for a, b in ((1, 2), (3, 4), (5, 6))]
         self.dense = [(mk('dense%d' % a), mk('dense%d' % b)) for a, b in ((1, 2), (3, 4))]
         self.gru = GruLayer(ctx, P, G, 'RNN.', name='dec%d' % self.uid)
-        # dense5 reads cat[out, rnn, emb5 x T] (model/model.py:357-358).  Its third K block multiplies a vector that is constant over
-        # time: W5[:, 2ch:] . emb5[c_b] is a per-SPEAKER bias table (n_spk x ch, one tiny GEMM per step) added in the epilogue of the
-        # GEMM over the first two blocks -- a third of this layer's forward, data-gradient and weight-gradient FLOPs (3.6 % of the
-        # step's) and the broadcast copy of emb5 disappear; the two column blocks are ConvLayers over views of the one parameter.
-        # ZS_FOLD_EMB5=1 (measured 1 % SLOWER at B = 256 bf16: 11.96 vs 11.85 ms -- the per-sample bias takes the GEMM off its fast
-        # register epilogue and adds six small launches to the chain, more than the saved third of the layer is worth under the
-        # power cap; kept as a tested option)
-        self.fold5 = os.environ.get('ZS_FOLD_EMB5', '0') == '1'
-        W5, gW5 = P['dense5.weight'], G['dense5.weight']
-        st5 = (W5.stride(0), 1, 0)
-        if self.fold5:
-            self.dense5 = ConvLayer(ctx, W5[:, :2 * c_h], P['dense5.bias'], gW5[:, :2 * c_h], G['dense5.bias'], pad_mode=self.pad_mode,
-                                    name='dense5', strides=st5)
-            self.dense5e = ConvLayer(ctx, W5[:, 2 * c_h:], None, gW5[:, 2 * c_h:], None, pad_mode=self.pad_mode, name='dense5e', strides=st5)
-        else:                                             # the literal cat[out, rnn, emb5 x T] GEMM (K = 3 c_h)
-            self.dense5, self.dense5e = mk('dense5'), None
+        self.dense5 = mk('dense5')                        # the literal cat[out, rnn, emb5 x T] GEMM (K = 3 c_h), model/model.py:357-358
         self.linear = mk('linear')
         self.emb = [P['emb%d.weight' % i] for i in range(1, 6)]
         self.gemb = [G['emb%d.weight' % i] for i in range(1, 6)]
         self.layers = [self.input_emb] + [l for p in self.convs for l in p] + [l for p in self.dense for l in p] + \
-            [self.dense5, self.linear] + ([self.dense5e] if self.fold5 else [])
+            [self.dense5, self.linear]
         self.tape = None
 
     def pack(self):
@@ -304,7 +275,7 @@ class DecoderEngine(_Taped):
             stt = self._in(yb, xn, xen, nxt, cidx, L.ZS_RES_UPSAMPLE2, x, training, 'c%d' % i)
             tp['blocks'].append((x, xe, ya, s, yb, stt, T))
             x, xe, T = xn, xen, 2 * T
-        cat3 = c.act('d_cat3' + tag, B, T, (2 if self.fold5 else 3) * ch)
+        cat3 = c.act('d_cat3' + tag, B, T, 3 * ch)
         for j, (la, lb) in enumerate(self.dense):                                                        # :333-342, :350-351
             y1 = c.act('d_y1%d' % j + tag, B, T, ch)
             y1e = c.act('d_y1e%d' % j + tag, B, T, ch)
@@ -319,28 +290,10 @@ class DecoderEngine(_Taped):
         H = ch // 2
         gi = c.act('d_gi' + tag, B, T, 6 * H)
         gates = c.raw('d_gates' + tag, B * T * 8 * H, c.tdt) if training else None
-        # capture-time hook (trainer.HostFedStep): a branch to run beside the GRU.  The hook marks the fork point and returns the
-        # launcher, which is called AFTER the main chain's next nodes are enqueued: the graph executor keeps the first-captured
-        # child of a node on the parent's queue, so the critical chain must be captured first (measured: otherwise the GRU waits
-        # for the whole fetch)
-        post = c.hooks['dec_gru_fwd']() if c.hooks.get('dec_gru_fwd') else None
         # :352-356, and append_emb (:357) rides on the recurrence's stores (third block of cat3 = emb5[c_b] at every t)
-        self.gru.fwd(xe, cat3, ch, gi, gates, bcast=(None if self.fold5 else (emb[4], cidx, 2 * ch)))
-        if post is not None:
-            post()
-        if not self.fold5:
-            h5 = c.act('d_h5' + tag, B, T, ch)
-            self.dense5.fwd(cat3, out=h5, act=LRELU, slope=ns)
-            return self._fwd_tail(c, tp, h5, cat3, gates, xe, T, tag, B)
-        # append_emb (:357) folded: pv[spk] = W5[:, 2ch:] . emb5[spk]  (fp32 table), added per sample in dense5's epilogue
-        e5 = c.act('d_e5rows_%d' % self.uid, 1, self.n_spk, ch)
-        L.call('zs_cast_rows', 'ZsCastRows', st, dtype=c.dt, src=L.ptr(emb[4]), ld_src=ch, src_f32=1, dst=e5.ptr(), ld_dst=e5.ld,
-               dst_f32=0, col_off=0, rows=self.n_spk, cols=ch, fill_cols=e5.ld, act=L.ZS_ACT_NONE)
-        pv = c.act('d_pv_%d' % self.uid, 1, self.n_spk, ch, dtype=torch.float32)
-        self.dense5e.fwd(e5, out=pv, out_f32=True)
-        pv_t = pv.t[:self.n_spk * pv.ld].view(self.n_spk, pv.ld)
+        self.gru.fwd(xe, cat3, ch, gi, gates, bcast=(emb[4], cidx, 2 * ch))
         h5 = c.act('d_h5' + tag, B, T, ch)
-        self.dense5.fwd(cat3, out=h5, act=LRELU, slope=ns, pre_vec=pv_t, idx=cidx)                       # :358-359
+        self.dense5.fwd(cat3, out=h5, act=LRELU, slope=ns)                                                # :358-359
         return self._fwd_tail(c, tp, h5, cat3, gates, xe, T, tag, B)
 
     def _fwd_tail(self, c, tp, h5, cat3, gates, xe, T, tag, B):
@@ -401,10 +354,10 @@ class DecoderEngine(_Taped):
         # append_emb's block of dense5 (model/model.py:357) multiplies a vector that is constant over time, so its input gradient
         # is only needed summed over t: sum_t (dz5[b,t] W5e) = (sum_t dz5[b,t]) W5e -- the column sums of dz5 (epilogue of the
         # GEMM that produces it) times the block, a B-row GEMM, instead of a third of dense5's data gradient
-        thin5 = fuse and not self.fold5 and ch % 128 == 0 and os.environ.get('ZS_THIN_EMB5', '1') == '1'
+        thin5 = fuse and ch % 128 == 0 and os.environ.get('ZS_THIN_EMB5', '1') == '1'
         self.linear.dgrad(dlogit, T, dz5, dact_src=h5, slope=ns, colsum=(slot(5) if thin5 else None), colsum_post=True)
         self.dense5.wgrad(dz5, cat3)
-        dcat3 = c.act('d_dcat3' + tag, B, T, (2 if self.fold5 else 3) * ch)
+        dcat3 = c.act('d_dcat3' + tag, B, T, 3 * ch)
         if thin5:
             self.dense5.dgrad(dz5, T, dcat3, n_cols=2 * ch)
             s32 = Act(self._embsum, B, 1, ch, ch, 5 * B * ch)
@@ -413,37 +366,20 @@ class DecoderEngine(_Taped):
                    dst_f32=0, col_off=0, rows=B, cols=ch, fill_cols=sT.ld, act=L.ZS_ACT_NONE)
             slot4 = Act(self._embsum, B, 1, ch, ch, 4 * B * ch)
             self.dense5.dgrad(sT, 1, slot4, add_src=slot4, out_f32=True, add_f32=True, n_cols=ch, n_off=2 * ch)
-        elif not self.fold5 and fuse:                                                        # d emb5 via append_emb: the third
+        elif fuse:                                                                           # d emb5 via append_emb: the third
             self.dense5.dgrad(dz5, T, dcat3, colsum=slot(4, 2 * ch), out_cols=2 * ch)        # column block is summed, not stored
         else:
             self.dense5.dgrad(dz5, T, dcat3)
-            if not self.fold5:
-                self._combine(dcat3.sub(2 * ch, ch), T, 0, 0, None, emb_i=4)
-        if self.fold5:
-            # the folded emb5 block: with s[b] = sum_t dz5[b, t, :]  (per-sample column sums, slot 5)
-            #   d emb5 (per sample, slot 4) += s[b] . W5[:, 2ch:]          d W5[:, 2ch:] (+)= sum_b s[b]^T emb5[c_b]
-            self._combine(Act(dz5.t, B, T, ch, dz5.ld), T, 0, 0, None, emb_i=5)
-            s32 = Act(self._embsum, B, 1, ch, ch, 5 * B * ch)
-            sT = c.act('d_s5' + tag, B, 1, ch)
-            L.call('zs_cast_rows', 'ZsCastRows', c.stream, dtype=c.dt, src=s32.ptr(), ld_src=ch, src_f32=1, dst=sT.ptr(), ld_dst=sT.ld,
-                   dst_f32=0, col_off=0, rows=B, cols=ch, fill_cols=sT.ld, act=L.ZS_ACT_NONE)
-            slot4 = Act(self._embsum, B, 1, ch, ch, 4 * B * ch)
-            self.dense5e.dgrad(sT, 1, slot4, add_src=slot4, out_f32=True, add_f32=True)
-            e5b = c.act('d_e5b' + tag, B, 1, ch)
-            L.call('zs_add_rowvec', 'ZsAddRowvec', c.stream, dtype=c.dt, x=None, vec=L.ptr(self.emb[4]), vec_ld=ch, idx=L.ptr(tp['cidx']),
-                   out=e5b.ptr(), ldo=e5b.ld, B=B, T=1, C=ch, fill_cols=e5b.ld)
-            self.dense5e.wgrad(sT, e5b)
+            self._combine(dcat3.sub(2 * ch, ch), T, 0, 0, None, emb_i=4)
         dgi = c.act('d_dgi' + tag, B, T, 6 * H)
         dgh = c.act('d_dgh' + tag, B, T, 6 * H)
         gp = c.act('d_gpA' + tag, B, T + 2, ch)
         gpv = Act(gp.t, B, T, ch, gp.ld)
-        post = c.hooks['dec_gru_bwd']() if c.hooks.get('dec_gru_bwd') else None
         dx = c.act('d_dxA' + tag, B, T, ch)
         if fuse:                                                                                     # out+emb5 (:353)
-            self.gru.bwd(dcat3, ch, cat3, ch, tp['gates'], tp['gru_in'], dgi, dgh, dx, add_src=dcat3.sub(0, ch), post_persist=post,
-                         colsum=slot(4))
+            self.gru.bwd(dcat3, ch, cat3, ch, tp['gates'], tp['gru_in'], dgi, dgh, dx, add_src=dcat3.sub(0, ch), colsum=slot(4))
         else:
-            self.gru.bwd(dcat3, ch, cat3, ch, tp['gates'], tp['gru_in'], dgi, dgh, gpv, post_persist=post)
+            self.gru.bwd(dcat3, ch, cat3, ch, tp['gates'], tp['gru_in'], dgi, dgh, gpv)
             self._combine(gpv, T, 0, 0, dx, emb_i=4, res_mode=L.ZS_RES_IDENTITY, res=dcat3.sub(0, ch))
         for j in (1, 0):
             la, lb = self.dense[j]
@@ -487,7 +423,7 @@ class DecoderEngine(_Taped):
         for k in range(5):
             st_k = sts[k % len(sts)].cuda_stream if sts is not None else c.stream
             L.call('zs_emb_scatter', 'ZsEmbScatter', st_k, emb_sum=L.ptr(self._embsum, k * B * ch), emb_ld=ch,
-                   idx=L.ptr(tp['cidx']), B=B, demb=L.ptr(self.gemb[k]), demb_ld=ch, n_rows=self.n_spk, C=ch, accumulate=int(c.accumulate))
+                   idx=L.ptr(tp['cidx']), B=B, demb=L.ptr(self.gemb[k]), demb_ld=ch, n_rows=self.n_spk, C=ch, accumulate=0)
         bits = tp['bits']
         self.input_emb.wgrad(dx, bits)
         dbits = None
@@ -497,7 +433,7 @@ class DecoderEngine(_Taped):
         return dbits
 
 
-class ClassifierEngine(_Taped):
+class ClassifierEngine(object):
     """SpeakerClassifier.forward (reference model/model.py:262-280) and its backward: four conv blocks on the
     T' = T/8 code sequence (conv k5/k3 + lrelu, InstanceNorm, Dropout, identity residual on blocks 2 and 3) and a
     final un-padded Conv1d whose kernel spans the whole sequence (k = seg_len/8) -> logits [B, n_class]."""

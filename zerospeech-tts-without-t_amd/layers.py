@@ -136,7 +136,7 @@ _LANE = {}
 
 
 def lane_stream(device, i):
-    """Stream of micro-batch lane i >= 1 (lane 0 runs on the caller's stream)."""
+    """Extra stream i >= 1 of a buffer set (see Ctx.lane; convert.encode_batch runs its length groups on several)."""
     key = (device.type, device.index, i)
     if key not in _LANE:
         _LANE[key] = torch.cuda.Stream(device)
@@ -170,12 +170,10 @@ class Ctx(object):
         self.kc = 128 // self.es
         self._bufs = {}
         self._ws = None
-        self.hooks = {}              # capture-time hooks of the engines (name -> callable or None)
-        # micro-batch lanes (trainer.AEStep): a lane has its own activation buffers and tape; the second lane ADDS its parameter
-        # gradients to the first one's (same side stream per layer: stream order makes the sum deterministic)
-        self.lane = ''
-        self.accumulate = False
-        self.pin_wgrad_streams = False   # lanes: a layer's weight gradients always go to the same side stream
+        self.lane = ''               # name of the current buffer set: launches on different streams must not share scratch buffers
+        # True: a layer's weight gradients always go to the same side stream (stage 2: several passes of a step accumulate into
+        # one gradient buffer, and stream order makes that sum deterministic)
+        self.pin_wgrad_streams = False
         # sticky status word of the persistent kernels (ZsGruFwd.status): OR-ed into on a bounded-spin timeout, never cleared by
         # the library; read at the host's own sync points by check_status()
         self.status = device_status(self.device)
@@ -325,7 +323,7 @@ class ConvLayer(object):
         kw = dict(dtype=c.dt, dY=dY.ptr(), ldy=dY.ld, y_cols=y_cols, X=X.ptr(), ldx=X.ld, x_batch_stride=X.T * X.ld,
                   x_cols=x_cols, B=X.B, T_in=X.T, T_out=dY.T, taps=self.k, stride=self.stride, pad_left=self.pad_l,
                   pad_mode=self.pad_mode, Cout=self.Cout, Cin=self.Cin, dW=L.ptr(self.gw), so=self.so, si=self.si, sj=self.sj,
-                  db=(L.ptr(self.gb) if bias else None), co_split2=int(self.split2), accumulate=int(accumulate or c.accumulate), splits=0)
+                  db=(L.ptr(self.gb) if bias else None), co_split2=int(self.split2), accumulate=int(accumulate), splits=0)
         wgrad_call(c, kw, self.sid)
 
 
@@ -338,8 +336,8 @@ def next_sid():
 
 
 def wgrad_call(ctx, kw, sid=None):
-    """sid: None = round robin over the side streams; an int pins the call to side stream sid % N (every weight gradient of one
-    parameter on ONE stream: with micro-batch lanes the second lane's accumulating launch is ordered behind the first's)."""
+    """sid: None = round robin over the side streams; with ctx.pin_wgrad_streams an int pins the call to side stream sid % N
+    (every weight gradient of one parameter on ONE stream: accumulating launches are ordered behind each other)."""
     S = L.STRUCTS['ZsGemmWgrad']
     s = S()
     for k, v in kw.items():
@@ -466,9 +464,8 @@ class GruLayer(object):
         """Test hook: raise if the last persistent pass over this layer's work buffer timed out (synchronises)."""
         L.check(L.lib().zs_gru_check(L.ptr(self._work(B)), B, self.H, self.ctx.stream), 'zs_gru_check')
 
-    def bwd(self, dout, dout_col, out, out_col, gates, X, dgi, dgh, dX, add_src=None, post_persist=None, colsum=None):
-        """BPTT + parameter gradients + input gradient dX (= dgi W_ih, + add_src).  post_persist: called right after the BPTT
-        launch (a capture-time hook: work that should run beside the persistent kernel)."""
+    def bwd(self, dout, dout_col, out, out_col, gates, X, dgi, dgh, dX, add_src=None, colsum=None):
+        """BPTT + parameter gradients + input gradient dX (= dgi W_ih, + add_src)."""
         c, H = self.ctx, self.H
         B, T = X.B, X.T
         work = self._work(B)
@@ -476,20 +473,18 @@ class GruLayer(object):
                out=out.ptr(), ldo=out.ld, out_col=out_col, gates=L.ptr(gates), whh_t=L.ptr(self.whh_t), ldw=self.hh_ldw_t,
                n_pad=self.hh_npad_t, w_gstride=self.hh_npad_t * self.hh_ldw_t, dgi=dgi.ptr(), ldgi=dgi.ld, dgh=dgh.ptr(),
                ldgh=dgh.ld, work=L.ptr(work), work_bytes=work.numel() * 4, status=L.ptr(c.status))
-        if post_persist is not None:
-            post_persist()
         for d in range(2):
             # dW_hh[d] = sum_t dgh_t^T h_{t-1}  (dir 0: h_{t-1} = out[t-1]; dir 1: out[t+1]) ; zero rows outside
             wgrad_call(c, dict(dtype=c.dt, dY=dgh.ptr(3 * H * d), ldy=dgh.ld, y_cols=3 * H, X=out.ptr(out_col + d * H),
                                ldx=out.ld, x_batch_stride=T * out.ld, x_cols=H, B=B, T_in=T, T_out=T, taps=1, stride=1,
                                pad_left=(1 if d == 0 else -1), pad_mode=L.ZS_PAD_ZERO, Cout=3 * H, Cin=H,
                                dW=L.ptr(self.gw_hh[d]), so=H, si=1, sj=0, db=L.ptr(self.gb_hh[d]), co_split2=0,
-                               accumulate=int(c.accumulate), splits=0), self.sids[2 * d])
+                               accumulate=0, splits=0), self.sids[2 * d])
             wgrad_call(c, dict(dtype=c.dt, dY=dgi.ptr(3 * H * d), ldy=dgi.ld, y_cols=3 * H, X=X.ptr(), ldx=X.ld,
                                x_batch_stride=T * X.ld, x_cols=min(X.cols, rup(self.Cin, 16 // c.es)), B=B, T_in=T, T_out=T,
                                taps=1, stride=1, pad_left=0, pad_mode=L.ZS_PAD_ZERO, Cout=3 * H, Cin=self.Cin,
                                dW=L.ptr(self.gw_ih[d]), so=self.Cin, si=1, sj=0, db=L.ptr(self.gb_ih[d]), co_split2=0,
-                               accumulate=int(c.accumulate), splits=0), self.sids[2 * d + 1])
+                               accumulate=0, splits=0), self.sids[2 * d + 1])
         kw = dict(dtype=c.dt, A=dgi.ptr(), lda=dgi.ld, a_batch_stride=T * dgi.ld, B=B, T_in=T, T_out=T, taps=1, stride=1,
                   pad_left=0, pad_mode=L.ZS_PAD_ZERO, gather=0, cin_pad=self.g6_pad, W=L.ptr(self.wih_d), ldw=self.ih_ldw_d,
                   N=self.Cin, n_pad=self.ih_npad_d, act=L.ZS_ACT_NONE, out=dX.ptr(), ldc=dX.ld,

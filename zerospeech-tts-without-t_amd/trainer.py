@@ -60,134 +60,29 @@ class AEStep(object):
         self._dec_updated = False
         self.fetch_by_kernel = os.environ.get('ZS_FETCH_KERNEL', '1') == '1'     # in-graph H2D by zs_host_fetch instead of a memcpy node
         self.fetch_wgs = int(os.environ.get('ZS_FETCH_WGS', '32'))
-        self.lanes = max(1, int(os.environ.get('ZS_LANES', '1')))                # micro-batch lanes (see _seg_forward_decbwd)
-        self._lane_loss, self._lane_part, self._lane_state = [], [], None
         self._graphs = {}            # (B, T, F) -> dict(graphs=[...], x=static x, c=static c)
         self._statics = {}           # (B, T, F) -> (x, c) handed out by static_inputs()
         self._eager_calls = 0
         self.graph_warmup = 2        # eager steps (same launches) before the capture
 
-    # ---- the three stream-ordered segments of a step -------------------------------------------------------------
-    # Micro-batch lanes (ZS_LANES = n > 1): the batch is cut into n slices that run the whole forward + backward as independent
-    # chains on their own streams (own activation buffers and tapes: layers.Ctx.lane).  A step is a strict alternation of
-    # MFMA-bound GEMMs with HBM-bound elementwise kernels and the latency-bound GRU recurrences; with two chains one lane's
-    # GEMMs fill the chip while the other sits in its GRU / normalisation phases.  Parameter gradients: lane 0 writes, the
-    # later lanes accumulate, every layer's weight gradients pinned to ONE side stream (stream order = summation order:
-    # deterministic).  The loss is the mean of the lane means; each lane's gradient is scaled by 1/n in zs_l1_loss.
-    def _lanes_for(self, B):
-        n = self.lanes
-        return n if (n > 1 and B % n == 0 and B >= 2 * n) else 1
-
-    def _set_lane(self, i, n):
-        for net in (self.Encoder, self.Decoder):
-            ctx = net._engine().ctx
-            ctx.lane = '' if n == 1 else 'L%d' % i
-            ctx.accumulate = i > 0
-            ctx.pin_wgrad_streams = n > 1
-
-    def _lane_streams(self, n):
-        main = torch.cuda.current_stream(self.device)
-        return [main] + [layers.lane_stream(self.device, i) for i in range(1, n)]
-
-    def _seg_forward_decbwd(self, x_btf, c, noise, noise_kind, drop_masks, seed, seed_ptr, join=True):
+    # ---- the stream-ordered segments of a step --------------------------------------------------------------------
+    def _seg_forward_decbwd(self, x_btf, c, noise, noise_kind, drop_masks, seed, seed_ptr):
         enc, dec = self.Encoder, self.Decoder
         ee, de = enc._engine(), dec._engine()
         ctx = ee.ctx
         B, T, F = x_btf.shape
-        n = self._lanes_for(B)
-        if n == 1:
-            self._set_lane(0, 1)
-            bits, _, _ = ee.forward(x_btf, True, noise=noise, noise_kind=noise_kind, seed=seed, drop_masks=drop_masks, seed_ptr=seed_ptr)
-            if getattr(self, '_after_encoder', None) is not None:
-                self._after_encoder()                                  # capture-time hook: fork the next batch's fetch here
-            xdec = de.forward(bits, c, True)
-            dlogit = de.ctx.act('t_dlogit_%d_%d' % (B, T), B, xdec.T, F)
-            L.call('zs_l1_loss', 'ZsL1Loss', ctx.stream, dtype=ctx.dt, x_dec=xdec.ptr(), ld_dec=xdec.ld, x=L.ptr(x_btf), ldx=F,
-                   rows=B * xdec.T, F=F, dlogits=dlogit.ptr(), ldg=dlogit.ld, fill_cols=dlogit.ld, partial=L.ptr(self._lpart),
-                   loss_out=L.ptr(self._loss), grad_scale=1.0)                                   # trainer.py:328
-            self._dbits = de.backward(dlogit)                                                    # loss.backward(), trainer.py:330
-            self.xdec = xdec
-            self._lane_state = None
-            return
-        Bl = B // n
-        streams = self._lane_streams(n)
-        main = streams[0]
-        ev0 = torch.cuda.Event()
-        ev0.record(main)
-        if len(self._lane_loss) < n:
-            self._lane_loss = [torch.zeros(1, dtype=torch.float32, device=self.device) for _ in range(n)]
-            self._lane_part = [torch.zeros(1024, dtype=torch.float32, device=self.device) for _ in range(n)]
-        st = []
-        stagger = os.environ.get('ZS_LANE_STAGGER', 'none')
-        ev_stag = None
-        for i in range(n):                                             # every lane's forward is issued before any backward: the side
-            s = streams[i]                                             # streams then see [bank convs of all lanes, weight gradients ...]
-            if i:
-                s.wait_event(ev0)
-                if ev_stag is not None:
-                    s.wait_event(ev_stag)
-            with torch.cuda.stream(s):
-                self._set_lane(i, n)
-                xs, cs = x_btf[i * Bl:(i + 1) * Bl], c[i * Bl:(i + 1) * Bl]
-                nz = noise[i * Bl:(i + 1) * Bl].contiguous() if noise is not None else None
-                dm = [m[i * Bl:(i + 1) * Bl].contiguous() if m is not None else None for m in drop_masks] if drop_masks is not None else None
-                lseed = (seed * n + i) if seed_ptr is not None else (seed + 7919 * i)
-                bits, _, _ = ee.forward(xs, True, noise=nz, noise_kind=noise_kind, seed=lseed, drop_masks=dm, seed_ptr=seed_ptr)
-                if i == 0 and stagger == 'enc':
-                    ev_stag = torch.cuda.Event(); ev_stag.record(s)
-                if i == 0 and getattr(self, '_after_encoder', None) is not None:
-                    self._after_encoder()
-                xdec = de.forward(bits, cs, True)
-                if i == 0 and stagger == 'dec':
-                    ev_stag = torch.cuda.Event(); ev_stag.record(s)
-                dlogit = de.ctx.act('t_dlogit_%d_%d' % (Bl, T), Bl, xdec.T, F)
-                L.call('zs_l1_loss', 'ZsL1Loss', s.cuda_stream, dtype=ctx.dt, x_dec=xdec.ptr(), ld_dec=xdec.ld, x=L.ptr(xs), ldx=F,
-                       rows=Bl * xdec.T, F=F, dlogits=dlogit.ptr(), ldg=dlogit.ld, fill_cols=dlogit.ld, partial=L.ptr(self._lane_part[i]),
-                       loss_out=L.ptr(self._lane_loss[i]), grad_scale=1.0 / n)
-                st.append({'xdec': xdec, 'dlogit': dlogit, 'stream': s})
-        for i in range(n):
-            with torch.cuda.stream(streams[i]):
-                self._set_lane(i, n)
-                st[i]['dbits'] = de.backward(st[i]['dlogit'])
-                st[i]['ev_dec'] = torch.cuda.Event()
-                st[i]['ev_dec'].record(streams[i])
-        self._set_lane(0, n)
-        self.xdec = st[0]['xdec']
-        self._lane_state = st
-        if join:                                                       # (a graph boundary follows: every lane stream must rejoin)
-            for i in range(1, n):
-                main.wait_event(st[i]['ev_dec'])
+        bits, _, _ = ee.forward(x_btf, True, noise=noise, noise_kind=noise_kind, seed=seed, drop_masks=drop_masks, seed_ptr=seed_ptr)
+        xdec = de.forward(bits, c, True)
+        dlogit = de.ctx.act('t_dlogit_%d_%d' % (B, T), B, xdec.T, F)
+        L.call('zs_l1_loss', 'ZsL1Loss', ctx.stream, dtype=ctx.dt, x_dec=xdec.ptr(), ld_dec=xdec.ld, x=L.ptr(x_btf), ldx=F,
+               rows=B * xdec.T, F=F, dlogits=dlogit.ptr(), ldg=dlogit.ld, fill_cols=dlogit.ld, partial=L.ptr(self._lpart),
+               loss_out=L.ptr(self._loss), grad_scale=1.0)                                   # trainer.py:328
+        self._dbits = de.backward(dlogit)                                                    # loss.backward(), trainer.py:330
+        self.xdec = xdec
 
     def _seg_encbwd(self):
-        st = getattr(self, '_lane_state', None)
-        if st is None:
-            self._set_lane(0, 1)
-            self.Encoder._engine().backward(self._dbits)
-            join_side(self.device)
-            return
-        n = len(st)
-        ee = self.Encoder._engine()
-        streams = self._lane_streams(n)
-        main = streams[0]
-        ev0 = torch.cuda.Event()
-        ev0.record(main)
-        for i in range(n):
-            s = streams[i]
-            if i:
-                s.wait_event(ev0)
-            with torch.cuda.stream(s):
-                self._set_lane(i, n)
-                ee.backward(st[i]['dbits'])
-                st[i]['ev_enc'] = torch.cuda.Event()
-                st[i]['ev_enc'].record(s)
-        for i in range(1, n):
-            main.wait_event(st[i]['ev_enc'])
-        self._set_lane(0, n)
+        self.Encoder._engine().backward(self._dbits)
         join_side(self.device)
-        self._loss.copy_(self._lane_loss[0])                           # mean of the lane means (trainer.py:328 over the whole batch)
-        for i in range(1, n):
-            self._loss.add_(self._lane_loss[i])
-        self._loss.mul_(1.0 / n)
 
     def step(self, x_btf, c, noise=None, noise_kind=2, drop_masks=None, seed=None, update=True):
         """x_btf: fp32 [B, T, F] on the device (the loader's native layout), c: int64 [B].
@@ -201,7 +96,7 @@ class AEStep(object):
             return self._graph_step(x_btf, c, multi)
         if seed is None:
             seed = (self.adam_step + 1) * 0x9E3779B97F4A7C15 % (1 << 63) + parallel.rank()
-        self._seg_forward_decbwd(x_btf, c, noise, noise_kind, drop_masks, seed, None, join=multi)
+        self._seg_forward_decbwd(x_btf, c, noise, noise_kind, drop_masks, seed, None)
         if multi:
             join_side(self.device)                 # decoder weight gradients (side stream) must be complete
             self.reducer.start(dec.flat_params()[1])
@@ -219,7 +114,7 @@ class AEStep(object):
         st = torch.cuda.current_stream(self.device).cuda_stream
         enc, dec = self.Encoder, self.Decoder
         L.check(L.lib().zs_step_counters(L.ptr(self._seed_dev), L.ptr(self._step_dev), st), 'zs_step_counters')
-        self._seg_forward_decbwd(x_btf, c, None, 2, None, parallel.rank(), L.ptr(self._seed_dev), join=multi)
+        self._seg_forward_decbwd(x_btf, c, None, 2, None, parallel.rank(), L.ptr(self._seed_dev))
         if multi:
             join_side(self.device)
             self.reducer.start(dec.flat_params()[1])
@@ -247,8 +142,7 @@ class AEStep(object):
         b1, b2 = self.betas
         L.call('zs_adam_clip', 'ZsAdam', st, p=L.ptr(flat), g=L.ptr(gflat), m=L.ptr(o['m']), v=L.ptr(o['v']),
                n=flat.numel(), lr=self.lr, beta1=b1, beta2=b2, eps=1e-8, bc1=1.0, bc2=1.0, sumsq=L.ptr(o['sq']),
-               max_norm=self.max_grad_norm, write_clipped_grad=0, step_ptr=L.ptr(self._step_dev), grad_scale=self.reducer.scale,
-               max_blocks=L.background_blocks())
+               max_norm=self.max_grad_norm, write_clipped_grad=0, step_ptr=L.ptr(self._step_dev), grad_scale=self.reducer.scale)
         net.repack()
 
     def _early_decoder_update(self):
@@ -259,12 +153,10 @@ class AEStep(object):
         ev_main = torch.cuda.Event()
         ev_main.record(main)
         os_.wait_event(ev_main)
-        for lane in (getattr(self, '_lane_state', None) or [])[1:]:
-            os_.wait_event(lane['ev_dec'])                         # every lane's decoder backward
         for ev in layers.side_events(self.device):
             os_.wait_event(ev)
-        with torch.cuda.stream(os_), L.background(int(os.environ.get('ZS_BG_BLOCKS', '0'))):
-            self._net_device_update('dec', self.Decoder)       # (ZS_BG_BLOCKS caps its grids: measured slower, 256: 12.1, 512: 11.7, 1024: 11.6 vs 11.46 ms uncapped)
+        with torch.cuda.stream(os_):
+            self._net_device_update('dec', self.Decoder)
         self._dec_updated = True
 
     def _optimizer_device_step(self):
@@ -330,66 +222,32 @@ class AEStep(object):
         def seg1():
             main = torch.cuda.current_stream(self.device)
             st = main.cuda_stream
-
-            def fork_prefetch(part=None, deferred=False):
-                """The fetch of the NEXT batch as a parallel branch of this graph.  part None: everything; 0 / 1: the index tensor +
-                the first / the second half of the spectrogram bytes.  deferred: mark the fork point now and return the launcher
-                (see DecoderEngine.forward: the critical chain's next nodes are captured before the branch)."""
+            if prefetch is not None:
+                # The fetch of the NEXT batch forks at the very start of the graph and joins at its very end: measured with kernel
+                # traces, wherever the branch forks the executor of this ROCm stack does not run it truly
+                # beside the chain (the 1.2 ms transfer costs 1.1-1.4 ms of step time); this placement is the cheapest.
                 cs_ = layers.copy_stream(self.device)
                 ev0 = torch.cuda.Event()
                 ev0.record(main)
-                if deferred:
-                    return lambda: launch_prefetch(part, cs_, ev0)
-                launch_prefetch(part, cs_, ev0)
-
-            def launch_prefetch(part, cs_, ev0):
                 cs_.wait_event(ev0)
                 with torch.cuda.stream(cs_):
-                    if self.fetch_by_kernel:                       # a kernel node that reads the pinned buffers over PCIe (zs_amd.h)
-                        nbx = prefetch[0].numel() * prefetch[0].element_size()
-                        half = (nbx // 2) // 16 * 16
-                        jobs = []
-                        if part in (None, 0):
-                            jobs.append((L.ptr(prefetch[3]), L.ptr(prefetch[2]), prefetch[2].numel() * prefetch[2].element_size()))
-                        lo, hi = (0, nbx) if part is None else ((0, half) if part == 0 else (half, nbx))
-                        jobs.append((L.ptr(prefetch[1]) + lo, L.ptr(prefetch[0]) + lo, hi - lo))
-                        for src, dst, nb in jobs:
-                            L.check(L.lib().zs_host_fetch(src, dst, nb, self.fetch_wgs, cs_.cuda_stream), 'zs_host_fetch')
-                    elif part in (None, 0):
+                    if self.fetch_by_kernel:                       # kernel nodes that read the pinned buffers over PCIe (zs_amd.h)
+                        for src, dst in ((prefetch[3], prefetch[2]), (prefetch[1], prefetch[0])):
+                            L.check(L.lib().zs_host_fetch(L.ptr(src), L.ptr(dst), dst.numel() * dst.element_size(), self.fetch_wgs,
+                                                          cs_.cuda_stream), 'zs_host_fetch')
+                    else:
                         prefetch[0].copy_(prefetch[1], non_blocking=True)
                         prefetch[2].copy_(prefetch[3], non_blocking=True)
                     state['ev'] = torch.cuda.Event()
                     state['ev'].record(cs_)
-
-            # Where the branch forks (ZS_FETCH_FORK = start | counters | encoder | gru): measured on this ROCm stack (DESIGN section 7)
-            # the graph executor does not run this branch truly beside the chain wherever it forks -- the 1.2 ms transfer costs
-            # 1.1-1.4 ms of step time; forking at the start and joining at the very end of the graph is the cheapest (12.99 vs
-            # 11.9 ms resident); `gru` puts the two halves beside the decoder's GRU forward / BPTT.
-            fork_at = os.environ.get('ZS_FETCH_FORK', 'start') if prefetch is not None else None
-            dctx = self.Decoder._engine().ctx
-            if fork_at == 'start':
-                fork_prefetch()
             L.check(L.lib().zs_step_counters(L.ptr(self._seed_dev), L.ptr(self._step_dev), st), 'zs_step_counters')
-            if fork_at == 'counters':
-                fork_prefetch()
-            self._after_encoder = fork_prefetch if fork_at == 'encoder' else None
-            if fork_at == 'gru':
-                if os.environ.get('ZS_FETCH_SPLIT', '1') == '1':
-                    dctx.hooks['dec_gru_fwd'] = lambda: fork_prefetch(0, True)
-                    dctx.hooks['dec_gru_bwd'] = lambda: fork_prefetch(1, True)
-                else:
-                    dctx.hooks['dec_gru_fwd'] = lambda: fork_prefetch(None, True)
-            try:
-                self._seg_forward_decbwd(xs, cs, None, 2, None, parallel.rank(), st_ptr, join=multi)
-            finally:
-                self._after_encoder = None
-                dctx.hooks.pop('dec_gru_fwd', None); dctx.hooks.pop('dec_gru_bwd', None)
+            self._seg_forward_decbwd(xs, cs, None, 2, None, parallel.rank(), st_ptr)
             if multi:
                 join_side(self.device)
+                join_prefetch()                                    # several graphs: the branch must end inside the first
             elif self.early_dec_update:
                 self._early_decoder_update()
-            if multi:
-                join_prefetch()                                    # three graphs: the branch must end inside the first
+
         def seg3():
             self._optimizer_device_step()
             self.adam_step = step0                             # capture does not execute: the caller counts the step
