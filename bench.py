@@ -451,9 +451,11 @@ def parity_record(enc, dec, dev, B=256):
         xd_f = dec32(act_f, c)
         xd_b_same = dec(act_f.clone(), c)
     rel = lambda a, r: float((a.float() - r.float()).abs().max() / r.float().abs().max())
+    rms = lambda a, r: float((a.float() - r.float()).norm() / r.float().norm())
     out = {'mbv_bit_mismatch_rate': float((act_b != act_f).float().mean()), 'mbv_bits_compared': int(act_f.numel()),
            'enc_logits_rel_err': rel(log_b, log_f), 'x_dec_rel_err': rel(xd_b_same, xd_f), 'x_dec_rel_err_end_to_end': rel(xd_b, xd_f),
-           'x_dec_mean_abs_err': float((xd_b_same - xd_f).abs().mean()),
+           'x_dec_mean_abs_err': float((xd_b_same - xd_f).abs().mean()), 'enc_logits_rel_rms_err': rms(log_b, log_f),
+           'x_dec_rel_rms_err': rms(xd_b_same, xd_f), 'x_dec_rel_rms_err_end_to_end': rms(xd_b, xd_f),
            'reference': 'fp32 HIP path (exact-fp32 MFMA; parity-tested against the oracle at 1e-3), same weights / batch of %d / Gumbel noise, eval mode' % B}
     enc.train(was[0]); dec.train(was[1])
     del enc32, dec32

@@ -121,6 +121,10 @@ def main(argv=None):
             trainer.add_duo_loader(source_loader, target_loader)
             trainer.train(model_path, args.flag, mode='patchGAN', target_guided=args.train_tgat)     # stage 2
             trainer.reset_keep()
+        if args.train and parallel.rank() == 0:
+            # reference main.py:163-173 goes on to the autolocker, t_classify and Tacotron stages: outside the path this build covers
+            print("[Runner] - --train ran the pretrain_AE and patchGAN stages; the reference's autolocker / t_classify / Tacotron "
+                  'stages are not part of this build and were skipped')
 
     if args.test or args.test_encode or args.test_single:
         os.makedirs(args.result_dir, exist_ok=True)

@@ -157,6 +157,48 @@ def test_config2_b256_bf16_default_dispatch_spot_checks(dev):
         got.append(float(gw[co, ci, j])); ref.append(float(prod.sum())); absref.append(float(prod.abs().sum()))
     _check('conv5.weight gradient (wgrad_p8, taps)', got, ref, absref, False)
 
+    # ---- (6) emb5.weight through the thin path (engine.py: ZS_THIN_EMB5, default at this width).  emb5 enters twice
+    #          (model/model.py:353, 357): added to the GRU input -> per-sample column sums of the RAW dgi W_ih GEMM output; and as
+    #          the third K block of dense5 -> (sum_t dz5[b, t]) W5[:, 2ch:] with the column sums rounded to bf16 for that B-row GEMM.
+    H = ch // 2
+    dgi = _rows(de.ctx.act('d_dgi' + tag, B, T, 6 * H)).view(B, T, -1)
+    dz5r = _rows(dz5).view(B, T, -1)
+    Wih = torch.cat([_bf(dec.RNN.weight_ih_l0.detach()), _bf(dec.RNN.weight_ih_l0_reverse.detach())], 0).cpu()    # [6H, ch]
+    W5e = _bf(dec.dense5.weight.detach()[:, 2 * ch:]).cpu()                                                          # [n, ch]
+    ge5 = dec.grad_view('emb5.weight')
+    cc = c.cpu().numpy()
+    spk_present = np.unique(cc)
+    got, ref, tol = [], [], []
+    for _ in range(24):
+        sp, col = int(spk_present[rng.randint(len(spk_present))]), int(rng.randint(ch))
+        bsel = torch.from_numpy(np.flatnonzero(cc == sp)).to(dev)
+        t1 = dgi[bsel][:, :, :6 * H].double().cpu() * Wih[:, col]                       # [nb, T, 6H]
+        S = _bf(dz5r[bsel][:, :, :ch].float().sum(1)).cpu()                             # [nb, ch]: fp32 column sums, stored as bf16
+        t2 = S * W5e[:, col]
+        got.append(float(ge5[sp, col])); ref.append(float(t1.sum() + t2.sum()))
+        # (the epilogue sums the bf16-staged output values: one output rounding per (b, t) term on top of the fp32 accumulation)
+        tol.append(2e-4 * float(t1.abs().sum()) + (2.0 ** -8) * float(t1.sum(-1).abs().sum()) + (2.0 ** -7) * float(t2.abs().sum()) + 1e-12)
+    got, ref, tol = np.array(got), np.array(ref), np.array(tol)
+    assert np.abs(ref).max() > 0
+    assert (np.abs(got - ref) <= tol).all(), 'emb5.weight gradient (thin path): worst |d|/tol = %.3g' % (np.abs(got - ref) / tol).max()
+
+    # ---- (7) the encoder's last data gradient: only the conv bank's 896 of conv2's 1409 input columns (the rest is the input
+    #          gradient the reference computes and drops, utils.py:43-45), masked by lrelu'(cat)
+    ee = enc._engine()
+    etag = '_%d_%d_%d' % (ee.uid, B, T)
+    c1, c2 = 128, 512
+    dz = _rows(ee.ctx.act('e_dzy2' + etag, B, T, c2))
+    dcat = _rows(ee.ctx.act('e_dcat' + etag, B, T, ee.ncat))
+    cat = _rows(ee.tape['cat'])
+    W2 = _bf(enc.conv2.weight.detach()[:, :, 0]).cpu()                                  # [512, 1409]
+    ms, ns_ = rng.randint(B * T, size=n_chk), rng.randint(7 * c1, size=n_chk)
+    got, ref, absref = [], [], []
+    for m, n in zip(ms, ns_):
+        prod = dz[m, :c2].double().cpu() * W2[:, n]
+        r = float(prod.sum()) * (1.0 if float(cat[m, n]) > 0 else 0.01)
+        got.append(float(dcat[m, n])); ref.append(r); absref.append(float(prod.abs().sum()))
+    _check('conv2 data gradient, conv-bank columns (p8m16, n_cols = 896)', got, ref, absref, True)
+
     # ---- the loss of repeated steps on one batch falls; determinism of the step at this size
     l0b = ae.step(x, c, seed=11, update=False).item()
     assert l0b == l0

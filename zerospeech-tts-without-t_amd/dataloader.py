@@ -51,8 +51,10 @@ class DevicePrefetcher(object):
     separate HIP stream while the current step runs; `next()` returns device tensors `(c int64[B], x fp32[B, seg_len, F])`
     that stay valid until the call after next (double buffering)."""
 
-    def __init__(self, loader, device, n_speakers=None):
-        self.loader, self.device, self.n_speakers = loader, torch.device(device), n_speakers
+    def __init__(self, loader, device, n_speakers=None, check=None):
+        """check: optional callable on the HOST index tensor of every batch (e.g. stage2.PatchGANStep.check_targets): range checks
+        happen here, where the indices are still host memory, not as device-to-host syncs inside the training step."""
+        self.loader, self.device, self.n_speakers, self.check = loader, torch.device(device), n_speakers, check
         self.stream = torch.cuda.Stream(self.device)
         self.slots = [None, None]            # (pinned c, pinned x, dev c, dev x, event)
         self.turn = 0
@@ -64,6 +66,8 @@ class DevicePrefetcher(object):
         c = c.long().contiguous()
         if self.n_speakers is not None and c.numel() and (int(c.min()) < 0 or int(c.max()) >= self.n_speakers):
             raise ValueError('speaker index outside [0, %d) in the batch' % self.n_speakers)   # would fault the GPU in the embedding lookups
+        if self.check is not None:
+            self.check(c)
         sl = self.slots[i]
         if sl is None or sl[1].shape != x.shape or sl[0].shape != c.shape:
             sl = [torch.empty(c.shape, dtype=torch.int64).pin_memory(), torch.empty(x.shape, dtype=torch.float32).pin_memory(),

@@ -63,6 +63,13 @@ class PatchGANStep(object):
         self._l1part = torch.zeros(1024, dtype=torch.float32, device=dev)
         self.step_no = 0
 
+    def check_targets(self, c_host):
+        """c_host: speaker indices of a target batch, still on the HOST.  Raises like the reference's Generator embedding would
+        for a speaker outside the target range (an index outside the table would read past it on the GPU)."""
+        lo, hi = self.shift, self.shift + int(self.Generator.c_a)
+        if c_host.numel() and (int(c_host.min()) < lo or int(c_host.max()) >= hi):
+            raise RuntimeError('This generator can only convert to target speakers!')
+
     # ---- gen_step (trainer.py:266-278) ---------------------------------------------------------------------------------------
     def gen_forward(self, x_btf, c, train_generator, noise=None, noise_kind=2, drop_masks=None, seed=None):
         """x_btf fp32 [B, T, F] (source batch), c int64 [B] target speakers -> x_gen fp32 [B, T_out, F] contiguous."""
@@ -74,9 +81,9 @@ class PatchGANStep(object):
             seed = (self.step_no * 0x9E3779B97F4A7C15 + 12345) % (1 << 62) + 7 * parallel.rank()
         bits, _, _ = ee.forward(x_btf, True, noise=noise, noise_kind=noise_kind, seed=seed, drop_masks=drop_masks)   # encode_step
         xd = de.forward(bits, c, False)                                       # Decoder(enc, c)
+        # c - shift_c (trainer.py:277-279).  The range of c is checked where the batch is still on the host (check_targets(),
+        # called once per host batch by the training loop / DevicePrefetcher): no device-to-host sync per step here
         cg = (c - self.shift) if self.shift else c
-        if bool((cg < 0).any()) or bool((cg >= gen.c_a).any()):
-            raise RuntimeError('This generator can only convert to target speakers!')
         m = ge.forward(bits, cg.contiguous(), train_generator)                # Generator(enc, c - shift_c)
         B, T = xd.B, xd.T
         F = de.F

@@ -612,7 +612,12 @@ class Trainer(object):
                               ('target_classifier', self.TargetClassifier, 'target_classifier')):
             if key in load_model_list:
                 try:
-                    net.load_state_dict(strip(all_model[key]))
+                    if key == 'target_classifier' and clf_path is not None:        # trainer.py:157-161: taken from ANOTHER checkpoint
+                        clf_model = torch.load(clf_path, map_location='cpu', weights_only=True)
+                        net.load_state_dict(strip(clf_model['target_classifier']))
+                        tag = 'target_classifier_another'
+                    else:
+                        net.load_state_dict(strip(all_model[key]))
                     if verbose:
                         print('[%s], ' % tag, end='')
                 except Exception as e:                                   # reference: bare except, prints [x - X]
@@ -695,7 +700,7 @@ class Trainer(object):
             if self.source_loader is None or self.target_loader is None:
                 raise RuntimeError('patchGAN needs add_duo_loader(source_loader, target_loader)')
             self._duo = (DevicePrefetcher(self.source_loader, self.device, n_speakers=self.hps.n_speakers),
-                         DevicePrefetcher(self.target_loader, self.device, n_speakers=self.hps.n_speakers))
+                         DevicePrefetcher(self.target_loader, self.device, n_speakers=self.hps.n_speakers, check=self.stage2().check_targets))
         return next(self._duo[0]), next(self._duo[1])
 
     def train(self, model_path, flag='train', mode='train', target_guided=False):
