@@ -98,6 +98,12 @@ typedef struct {
    * One owner per (b, n): plain read-modify-write, no atomics.  Needs T_out | 128 (whole samples per tile). */
   float* colsum; int64_t colsum_ld; int32_t colsum_col0;
   int32_t colsum_post;             /* 1: sum the STORED value (after dact_src / add_src) instead */
+  /* ragged batch (inference: the tail fragments of convert.py:154-165 have 128..254 frames each and the reference runs them one
+   * by one): sample b has lengths[b] <= T_in valid input rows and (lengths[b] + pad_left + pad_right - taps) / stride + 1 valid
+   * output rows; the padding (reflect / zero) is applied at EACH sample's own end, exactly as if the sample ran alone.  Output
+   * rows past a sample's length are computed from zero rows (finite, never read by a length-aware consumer).  T_in / T_out stay
+   * the row strides of the batch.  gather 0 only; B < 65536, T_in < 32768.  null = every sample has T_in rows. */
+  const int32_t* lengths; int32_t pad_right;
 } ZsGemmConv;
 int zs_gemm_conv(const ZsGemmConv* p, void* stream);
 
@@ -201,6 +207,10 @@ typedef struct {
   float drop_p; uint64_t seed; uint32_t stream_id; const uint8_t* mask; int64_t mask_ld;
   int32_t res_mode; const void* res; int64_t ldres; int32_t T_res; int32_t res_pad_mode;
   const uint64_t* seed_ptr;      /* optional device scalar added to `seed` (graph replay: see zs_step_counters) */
+  /* ragged batch: the statistics of sample b run over its first lengths[b] <= T rows (T stays the row stride); rows past the
+   * length are written as zeros.  res_lengths[b] <= T_res: valid rows of the ZS_RES_AVGPOOL2 residual (its odd-length
+   * reflect / zero pad, model/model.py:424, happens at the sample's own end).  null = T / T_res for every sample. */
+  const int32_t* lengths; const int32_t* res_lengths;
 } ZsInstNormFwd;
 int zs_instnorm_fwd(const ZsInstNormFwd* p, void* stream);
 
@@ -304,12 +314,26 @@ typedef struct {
    * concatenation the GRU output goes into): out[b][t][bcast_col + c] = bcast_vec[bcast_idx[b]][c] for c < 2H and every t.
    * The persistent kernel is latency-bound and leaves HBM idle, so these 64 MB cost nothing there. */
   const float* bcast_vec; int64_t bcast_ld; const int64_t* bcast_idx; int32_t bcast_col;
+  /* 1: direction 1 also steps through t = 0 .. T-1 (instead of T-1 .. 0).  Ragged batches: the caller reverses the rows of
+   * every sample over ITS OWN length (zs_rows_reverse) in the direction-1 columns of gi before and of out after this call, so
+   * both directions are forward recurrences whose first lengths[b] steps are exactly the sample's own sequence. */
+  int32_t dir1_forward;
 } ZsGruFwd;
 size_t zs_gru_work_bytes(int32_t B, int32_t H);
 int zs_gru_fwd(const ZsGruFwd* p, void* stream);
 /* test / debug hook (synchronises the stream): ZS_OK unless the last persistent pass over `work` had a workgroup give up
  * waiting for its group -- bounded spins instead of a hang; the results of that pass are then invalid */
 int zs_gru_check(const float* work, int32_t B, int32_t H, void* stream);
+
+/* zs_rows_reverse: in-place reversal of the rows of every sample over its own length, restricted to a column block:
+ *   x[b][t][col0 + c] <-> x[b][lengths[b] - 1 - t][col0 + c]   for t < lengths[b] / 2, c < cols   (rows b*T + t, pitch ld elements)
+ * (nn.GRU's reverse direction on a ragged batch, see ZsGruFwd.dir1_forward).  cols * element size must be a multiple of 4. */
+typedef struct {
+  int32_t dtype;
+  void* x; int64_t ld; int32_t col0, cols;
+  int32_t B, T; const int32_t* lengths;
+} ZsRowsReverse;
+int zs_rows_reverse(const ZsRowsReverse* p, void* stream);
 typedef struct {
   int32_t dtype;
   int32_t B, T, H;

@@ -303,6 +303,130 @@ def test_dgrad_epilogue_mask_add_colsum(zs, dtype, shape, gemm_variant):
         assert (cs[:, Cin - c0:] == 0.5).all()
 
 
+# ---- ragged batches (per-sample lengths): every sample must come out exactly as if it had been launched alone ---------------
+
+RAGGED_LENS = [40, 9, 17, 33, 24, 40, 12]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', [(80, 48, 3, 1), (64, 256, 5, 1), (64, 48, 5, 2), (32, 40, 4, 1), (513, 128, 7, 1), (96, 256, 2, 1)])
+def test_conv_ragged_batch_equals_each_sample_alone(zs, dtype, case, gemm_variant):
+    """ZsGemmConv.lengths: reflect padding at each sample's own end (the reference forwards the 128..254-frame tail fragments one
+    by one, convert.py:154-165).  The valid rows of the ragged launch equal the launch of that sample alone BIT FOR BIT (same
+    kernel variant, same K order), and the fp32 torch reference to the usual tolerance."""
+    L, layers = zs
+    Cin, Cout, k, stride = case
+    lens = RAGGED_LENS
+    B, Tm = len(lens), max(lens)
+    g = torch.Generator().manual_seed(11 + k)
+    x = torch.randn(B, Tm, Cin, generator=g)
+    w = torch.randn(Cout, Cin, k, generator=g) / math.sqrt(Cin * k)
+    b = torch.randn(Cout, generator=g)
+    ctx = _ctx(layers, dtype)
+    l = _mk_conv(layers, ctx, w, b, stride=stride, pad_mode=L.ZS_PAD_REFLECT)
+    A = _to_act(layers, ctx, 'rx', x)
+    To = l.t_out(Tm)
+    out = ctx.act('ry', B, To, Cout)
+    out.t.fill_(float('nan'))
+    lens_d = torch.tensor(lens, dtype=torch.int32, device=ctx.device)
+    l.fwd(A, out=out, act=L.ZS_ACT_LRELU, slope=0.01, lengths=lens_d)
+    torch.cuda.synchronize()
+    got = out.valid().float().cpu()
+    assert torch.isfinite(got).all(), 'rows past a length must be finite (computed from zero rows)'
+    for i, n in enumerate(lens):
+        Ai = _to_act(layers, ctx, 'rx1_%d' % n, x[i:i + 1, :n])
+        to = l.t_out(n)
+        oi = ctx.act('ry1_%d' % n, 1, to, Cout)
+        l.fwd(Ai, out=oi, act=L.ZS_ACT_LRELU, slope=0.01)
+        torch.cuda.synchronize()
+        alone = oi.valid().float().cpu()[0]
+        assert torch.equal(got[i, :to], alone), 'sample %d (length %d): ragged launch differs from the sample alone' % (i, n)
+        ref = F.leaky_relu(_ref_conv(_round(x[i:i + 1, :n], dtype), _round(w, dtype), b, stride, True), 0.01)[0]
+        _close('ragged conv vs torch', got[i, :to], ref, _tol(dtype))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('res', ['none', 'identity', 'avgpool', 'upsample'])
+def test_instnorm_ragged_batch_equals_each_sample_alone(zs, dtype, res):
+    """ZsInstNormFwd.lengths / res_lengths: statistics over each sample's own rows; the avg-pool residual's odd-length pad at
+    the sample's own end.  Bit-identical to the sample alone; rows past a length are zeros."""
+    L, layers = zs
+    lens = [20, 9, 13, 20, 2, 7]
+    B, Tm, C = len(lens), max(lens), 40
+    g = torch.Generator().manual_seed(5)
+    x = _round(torch.randn(B, Tm, C, generator=g), dtype)
+    rlens = {'none': lens, 'identity': lens, 'avgpool': [2 * n - (i % 2) for i, n in enumerate(lens)], 'upsample': None}[res]
+    if res == 'upsample':
+        lens = [2 * (n // 2 + 1) for n in lens]                        # even lengths; residual rows = length / 2
+        Tm = max(lens)
+        x = _round(torch.randn(B, Tm, C, generator=g), dtype)
+        rlens = [n // 2 for n in lens]
+    Trm = {'none': Tm, 'identity': Tm, 'avgpool': 2 * Tm, 'upsample': Tm // 2}[res]
+    r = _round(torch.randn(B, Trm, C, generator=g), dtype)
+    mode = {'none': L.ZS_RES_NONE, 'identity': L.ZS_RES_IDENTITY, 'avgpool': L.ZS_RES_AVGPOOL2, 'upsample': L.ZS_RES_UPSAMPLE2}[res]
+    ctx = _ctx(layers, dtype)
+    X, R = _to_act(layers, ctx, 'nx', x), _to_act(layers, ctx, 'nr', r)
+    out = ctx.act('no', B, Tm, C)
+    out.t.fill_(float('nan'))
+    ld_, rl_ = torch.tensor(lens, dtype=torch.int32, device=ctx.device), torch.tensor(rlens, dtype=torch.int32, device=ctx.device)
+    L.call('zs_instnorm_fwd', 'ZsInstNormFwd', ctx.stream, dtype=ctx.dt, x=X.ptr(), ldx=X.ld, out=out.ptr(), ldo=out.ld, B=B, T=Tm, C=X.ld,
+           eps=1e-5, drop_p=0.0, res_mode=mode, res=R.ptr(), ldres=R.ld, T_res=Trm, res_pad_mode=L.ZS_PAD_REFLECT,
+           lengths=L.ptr(ld_), res_lengths=(L.ptr(rl_) if res == 'avgpool' else None))
+    torch.cuda.synchronize()
+    got = out.valid().float().cpu()
+    for i, n in enumerate(lens):
+        Xi = _to_act(layers, ctx, 'nx1_%d' % n, x[i:i + 1, :n])
+        Ri = _to_act(layers, ctx, 'nr1_%d' % rlens[i], r[i:i + 1, :rlens[i]])
+        oi = ctx.act('no1_%d' % n, 1, n, C)
+        L.call('zs_instnorm_fwd', 'ZsInstNormFwd', ctx.stream, dtype=ctx.dt, x=Xi.ptr(), ldx=Xi.ld, out=oi.ptr(), ldo=oi.ld, B=1, T=n, C=Xi.ld,
+               eps=1e-5, drop_p=0.0, res_mode=mode, res=Ri.ptr(), ldres=Ri.ld, T_res=rlens[i], res_pad_mode=L.ZS_PAD_REFLECT)
+        torch.cuda.synchronize()
+        assert torch.equal(got[i, :n], oi.valid().float().cpu()[0]), (res, i, n)
+        assert (got[i, n:] == 0).all()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(24, 16), (64, 128), (96, 512)])
+def test_gru_ragged_batch_equals_each_sample_alone(zs, dtype, shape):
+    """GruLayer.fwd(lengths=...): zs_rows_reverse on the reverse direction's gate inputs, both directions as forward recurrences
+    (ZsGruFwd.dir1_forward), outputs reversed back -- the valid rows of every sample equal the bidirectional GRU run on that
+    sample alone with T = its length (per-step, narrow and wide persistent kernels, whichever the shape dispatches to)."""
+    L, layers = zs
+    Cin, H = shape
+    if dtype == 'fp32' and H == 512:
+        pytest.skip('covered in bf16 (the fp32 H = 512 recurrence runs one launch per step: slow)')
+    lens = [12, 3, 7, 12, 2, 9, 5, 11, 4]
+    B, Tm = len(lens), max(lens)
+    g = torch.Generator().manual_seed(3)
+    gru = torch.nn.GRU(Cin, H, bidirectional=True)
+    P = {'RNN.' + k: v.detach().clone().to('cuda:0') for k, v in gru.state_dict().items()}
+    G = {k: torch.zeros_like(v) for k, v in P.items()}
+    ctx = _ctx(layers, dtype)
+    layer = layers.GruLayer(ctx, P, G, 'RNN.', name='rag')
+    layer.pack()
+    x = torch.randn(B, Tm, Cin, generator=g)
+    X = _to_act(layers, ctx, 'gx', x)
+    out = ctx.act('gout', B, Tm, 2 * H)
+    out.t.zero_()
+    gi = ctx.act('ggi', B, Tm, 6 * H)
+    lens_d = torch.tensor(lens, dtype=torch.int32, device=ctx.device)
+    layer.fwd(X, out, 0, gi, None, lengths=lens_d)
+    layer.check(B)
+    got = out.valid().float().cpu()
+    for i, n in enumerate(lens):
+        Xi = _to_act(layers, ctx, 'gx1_%d' % n, x[i:i + 1, :n])
+        oi = ctx.act('gout1_%d' % n, 1, n, 2 * H)
+        gii = ctx.act('ggi1_%d' % n, 1, n, 6 * H)
+        layer.fwd(Xi, oi, 0, gii, None)
+        torch.cuda.synchronize()
+        alone = oi.valid().float().cpu()[0]
+        # the ragged launch and the single-sample launch may take different kernels (batch 9 vs 1): compare to rounding
+        _close('ragged GRU sample %d (length %d)' % (i, n), got[i, :n], alone, 2e-5 if dtype == 'fp32' else 2e-2)
+        with torch.no_grad():
+            ref = gru(_round(x[i, :n], dtype).unsqueeze(1))[0][:, 0]
+        _close('ragged GRU vs nn.GRU sample %d' % i, got[i, :n], ref, 1e-4 if dtype == 'fp32' else 4e-2)
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('res', ['none', 'identity', 'avgpool', 'avgpool_odd', 'upsample'])
 def test_instnorm(zs, dtype, res):

@@ -274,59 +274,43 @@ def encode_batch(specs, trainer, seg_len, decode_speakers=None, noise_fn=None, m
         else:
             for k, (a, b) in enumerate(fragments(len(spec), seg_len)):
                 items.append((u, k, a, b, None))
-    by_len = {}
-    for it in items:
-        by_len.setdefault(it[3] - it[2], []).append(it)
+    # Two kinds of batches instead of one per distinct length (the fragment rule leaves ~60 tail lengths per 64 utterances):
+    # the full seg_len fragments as plain batches, everything else (tails of seg_len .. 2 seg_len - 2 frames, short utterances)
+    # as RAGGED batches padded to their longest member, with per-sample lengths: the kernels pad / normalise / run the reverse
+    # GRU at each sample's own end, so a fragment's result does not depend on what it is batched with.
+    full = [it for it in items if it[3] - it[2] == seg_len]
+    rest = sorted((it for it in items if it[3] - it[2] != seg_len), key=lambda it: it[2] - it[3])      # longest first
+    chunks = [(full[lo:lo + max_batch], None) for lo in range(0, len(full), max_batch)]
+    chunks += [(rest[lo:lo + max_batch], True) for lo in range(0, len(rest), max_batch)]
     enc_out, dec_out = {}, {}
-    pending = []                                          # (chunk, device encodings, device spectrograms): one host sync at the end
-    # The fragment rule leaves ~60 distinct tail lengths, each its own small batch whose time is the latency of its GRU
-    # recurrences (T steps of ~6 us, a few workgroups wide): the length groups go round robin over ZS_INFER_STREAMS streams, each
-    # with its own activation buffers (layers.Ctx.lane), so several recurrences are in flight at once.  The largest group (the
-    # full seg_len fragments, up to max_batch rows: a chip-wide GRU grid) runs first, alone.
-    from . import layers
-    n_streams = max(1, int(os.environ.get('ZS_INFER_STREAMS', '4')))
-    main = torch.cuda.current_stream(dev)
-    streams = [main] + [layers.lane_stream(dev, 100 + i) for i in range(1, n_streams)]
-    ctxs = [enc._engine().ctx, dec._engine().ctx]
-    groups = sorted(by_len.items(), key=lambda kv: -len(kv[1]))
-    ev0 = torch.cuda.Event()
-    gi = 0
-    try:
-        for Tf, group in groups:
-            for lo in range(0, len(group), max_batch):
-                chunk = group[lo:lo + max_batch]
-                k = 0 if (gi == 0 or n_streams == 1) else 1 + (gi - 1) % (n_streams - 1)
-                if gi == 1:                               # the small groups start once the big one has been issued
-                    ev0.record(main)
-                    for s in streams[1:]:
-                        s.wait_event(ev0)
-                gi += 1
-                for cx in ctxs:
-                    cx.lane = '' if k == 0 else 'S%d' % k
-                with torch.cuda.stream(streams[k]):
-                    xh = torch.from_numpy(np.stack([padded[u][a:b] for (u, _, a, b, _) in chunk]))                  # [n, Tf, 513]
-                    ch = torch.tensor([decode_speakers[u] for (u, _, _, _, _) in chunk], dtype=torch.int64) if decode_speakers is not None else None
-                    x = xh.to(dev, non_blocking=True)
-                    G = noise_fn(len(chunk), ((((Tf + 1) // 2 + 1) // 2) + 1) // 2, enc.enc_size) if noise_fn is not None else None
-                    act, _ = enc(x.permute(0, 2, 1), G=G)
-                    xd = None
-                    if ch is not None:
-                        xd = dec(act, ch.to(dev, non_blocking=True)).permute(0, 2, 1).contiguous()
-                    pending.append((chunk, act.permute(0, 2, 1).contiguous(), xd))
-    finally:
-        for cx in ctxs:
-            cx.lane = ''
-    for s in streams[1:]:
-        ev = torch.cuda.Event()
-        ev.record(s)
-        main.wait_event(ev)
-    for chunk, e_dev, xd_dev in pending:
+    pending = []                                          # (chunk, lengths, device encodings, device spectrograms): one host sync at the end
+    for chunk, ragged in chunks:
+        lens = [b - a for (_, _, a, b, _) in chunk]
+        Tm = max(lens)
+        if ragged:
+            xh = np.zeros((len(chunk), Tm, padded[0].shape[1]), dtype=np.float32)
+            for i, (u, _, a, b, _) in enumerate(chunk):
+                xh[i, :b - a] = padded[u][a:b]
+        else:
+            xh = np.stack([padded[u][a:b] for (u, _, a, b, _) in chunk])                               # [n, seg_len, 513]
+        x = torch.from_numpy(xh).to(dev, non_blocking=True)
+        Tp = ((((Tm + 1) // 2 + 1) // 2) + 1) // 2
+        G = noise_fn(len(chunk), Tp, enc.enc_size) if noise_fn is not None else None
+        act, _ = enc(x.permute(0, 2, 1), G=G, lengths=(lens if ragged else None))
+        xd = None
+        if decode_speakers is not None:
+            ch = torch.tensor([decode_speakers[u] for (u, _, _, _, _) in chunk], dtype=torch.int64)
+            lens_p = [((((n + 1) // 2 + 1) // 2) + 1) // 2 for n in lens]
+            xd = dec(act, ch.to(dev, non_blocking=True), lengths=(lens_p if ragged else None)).permute(0, 2, 1)
+        pending.append((chunk, lens, act.permute(0, 2, 1), xd))
+    for chunk, lens, e_dev, xd_dev in pending:
         e = e_dev.cpu().numpy()
         xd = (xd_dev.cpu().numpy() if to_host else xd_dev) if xd_dev is not None else None
         for i, (u, k, _, _, trunc) in enumerate(chunk):
-            enc_out[(u, k)] = e[i][:trunc] if trunc is not None else e[i]
+            tp = ((((lens[i] + 1) // 2 + 1) // 2) + 1) // 2
+            enc_out[(u, k)] = e[i][:trunc] if trunc is not None else e[i][:tp]
             if xd is not None:
-                dec_out[(u, k)] = xd[i]
+                dec_out[(u, k)] = xd[i][:8 * tp]
     from . import layers
     layers.check_status(dev)                                  # the .cpu() copies synchronised: a timed-out GRU pass raises here
     encs, decs = [], ([] if decode_speakers is not None else None)

@@ -468,6 +468,24 @@ inline unsigned nblocks(int64_t total, int cap = 2048) {
     else hipLaunchKernelGGL(KERNEL<bf16_t>, grid, block, 0, (hipStream_t)(stream), __VA_ARGS__);          \
   } while (0)
 
+// in-place per-sample row reversal over a column block (zs_rows_reverse): one thread per (sample, row pair, 4-byte word)
+__global__ __launch_bounds__(NTE) void rows_reverse_kernel(const ZsRowsReverse p, int words, int64_t ld_bytes, int64_t col_bytes) {
+  const int half = p.T >> 1;
+  const int64_t total = (int64_t)p.B * half * words;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int w = (int)(i % words);
+    const int64_t r = i / words;
+    const int t = (int)(r % half), b = (int)(r / half);
+    const int len = p.lengths ? p.lengths[b] : p.T;
+    if (t >= (len >> 1)) continue;
+    unsigned char* base = (unsigned char*)p.x + col_bytes + (int64_t)w * 4;
+    uint32_t* lo = reinterpret_cast<uint32_t*>(base + ((int64_t)b * p.T + t) * ld_bytes);
+    uint32_t* hi = reinterpret_cast<uint32_t*>(base + ((int64_t)b * p.T + (len - 1 - t)) * ld_bytes);
+    const uint32_t a = *lo, c = *hi;
+    *lo = c; *hi = a;
+  }
+}
+
 static int pack_check(const ZsPackWeight* p) {
   ZS_REQUIRE(p && p->W && p->dst, "zs_pack_weight: null operand");
   ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_pack_weight: bad dtype");
@@ -559,6 +577,19 @@ extern "C" int zs_add_rowvec(const ZsAddRowvec* p, void* stream) {
   }
   ZS_DISPATCH(p->dtype, add_rowvec_kernel, dim3(nblocks((int64_t)p->B * p->T * p->fill_cols, 4096)), dim3(NTE), stream, *p);
   return zs_check_launch("zs_add_rowvec");
+}
+
+extern "C" int zs_rows_reverse(const ZsRowsReverse* p, void* stream) {
+  ZS_REQUIRE(p && p->x && p->B > 0 && p->T > 0 && p->cols > 0 && p->col0 >= 0 && p->ld >= (int64_t)p->col0 + p->cols, "zs_rows_reverse: bad args");
+  ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_rows_reverse: bad dtype");
+  const int es = p->dtype == ZS_F32 ? 4 : 2;
+  ZS_REQUIRE((p->cols * es) % 4 == 0 && (p->col0 * es) % 4 == 0 && (p->ld * es) % 4 == 0 && (((uintptr_t)p->x) & 3) == 0,
+             "zs_rows_reverse: the column block must be made of whole 4-byte words");
+  if (p->T < 2) return ZS_OK;
+  const int words = p->cols * es / 4;
+  hipLaunchKernelGGL(rows_reverse_kernel, dim3(nblocks((int64_t)p->B * (p->T >> 1) * words, 4096)), dim3(NTE), 0, (hipStream_t)stream, *p, words,
+                     (int64_t)p->ld * es, (int64_t)p->col0 * es);
+  return zs_check_launch("zs_rows_reverse");
 }
 
 extern "C" int zs_emb_scatter(const ZsEmbScatter* p, void* stream) {

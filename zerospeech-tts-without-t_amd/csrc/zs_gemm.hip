@@ -58,6 +58,22 @@ __device__ __forceinline__ int conv_src_row(int gather, int pad_mode, int stride
   return q;
 }
 
+// (sample, position) of output row m for the A-row loaders.  rb < 0: the row contributes zeros (beyond M, or beyond its sample's
+// length in a ragged batch).  With p.lengths the sample's own input length rides in the upper half of rb (see conv_row_*).
+__device__ __forceinline__ void conv_row_setup(const ZsGemmConv& p, int m, int M, int& rb, int& rt) {
+  if (m >= M) { rb = -1; rt = 0; return; }
+  const int b = m / p.T_out;
+  rt = m - b * p.T_out;
+  rb = b;
+  if (p.lengths) {
+    const int len = p.lengths[b];
+    const int len_out = (len + p.pad_left + p.pad_right - p.taps) / p.stride + 1;
+    rb = (rt < len_out) ? ((len << 16) | b) : -1;
+  }
+}
+__device__ __forceinline__ int conv_row_b(const ZsGemmConv& p, int rb) { return p.lengths ? (rb & 0xffff) : rb; }
+__device__ __forceinline__ int conv_row_tin(const ZsGemmConv& p, int rb) { return p.lengths ? (rb >> 16) : p.T_in; }
+
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
   static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
@@ -321,7 +337,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_conv_kernel(const ZsGemmConv p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int m = m0 + r0 + 32 * i;
-    if (m < M) { rb[i] = m / p.T_out; rt[i] = m - rb[i] * p.T_out; } else { rb[i] = -1; rt[i] = 0; }
+    conv_row_setup(p, m, M, rb[i], rt[i]);
   }
   const int chunks_per_tap = p.cin_pad / KC;
   const T* zline = reinterpret_cast<const T*>(zs_zero_line) + seg * EPS;
@@ -330,8 +346,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_conv_kernel(const ZsGemmConv p) {
 #define ZS_SET_TAP(i, ptr, inc)                                                                         \
   {                                                                                                     \
     bool ok = false; int srow = 0;                                                                      \
-    if (rb[i] >= 0) srow = conv_src_row(p.gather, p.pad_mode, p.stride, p.pad_left, p.T_in, rt[i], tap, ok); \
-    ptr = ok ? (A + (int64_t)rb[i] * p.a_batch_stride + (int64_t)srow * p.lda + seg * EPS) : zline;       \
+    if (rb[i] >= 0) srow = conv_src_row(p.gather, p.pad_mode, p.stride, p.pad_left, conv_row_tin(p, rb[i]), rt[i], tap, ok); \
+    ptr = ok ? (A + (int64_t)conv_row_b(p, rb[i]) * p.a_batch_stride + (int64_t)srow * p.lda + seg * EPS) : zline;       \
     inc = ok ? KC : 0;                                                                                  \
   }
   const T* pw0 = W + (int64_t)(n0 + r0) * p.ldw + seg * EPS;
@@ -461,7 +477,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_conv_dma_kernel(const ZsGemmConv p
     const int r = wave * 32 + i * 8 + lrow;
     lseg[i] = slot ^ ((r >> 1) & 7);
     const int m = m0 + r;
-    if (m < M) { rb[i] = m / p.T_out; rt[i] = m - rb[i] * p.T_out; } else { rb[i] = -1; rt[i] = 0; }
+    conv_row_setup(p, m, M, rb[i], rt[i]);
   }
   const int chunks_per_tap = p.cin_pad / KC;
   const T* zline = reinterpret_cast<const T*>(zs_zero_line);
@@ -470,8 +486,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_conv_dma_kernel(const ZsGemmConv p
 #define ZS_SET_TAP(i, ptr, inc)                                                                         \
   {                                                                                                     \
     bool ok = false; int srow = 0;                                                                      \
-    if (rb[i] >= 0) srow = conv_src_row(p.gather, p.pad_mode, p.stride, p.pad_left, p.T_in, rt[i], tap, ok); \
-    ptr = ok ? (A + (int64_t)rb[i] * p.a_batch_stride + (int64_t)srow * p.lda + lseg[i] * EPS) : (zline + lseg[i] * EPS); \
+    if (rb[i] >= 0) srow = conv_src_row(p.gather, p.pad_mode, p.stride, p.pad_left, conv_row_tin(p, rb[i]), rt[i], tap, ok); \
+    ptr = ok ? (A + (int64_t)conv_row_b(p, rb[i]) * p.a_batch_stride + (int64_t)srow * p.lda + lseg[i] * EPS) : (zline + lseg[i] * EPS); \
     inc = ok ? KC : 0;                                                                                  \
   }
   const T* pw0 = W + (int64_t)(n0 + wave * 32 + lrow) * p.ldw + lseg[0] * EPS;
@@ -594,7 +610,7 @@ __global__ __launch_bounds__(RNT, 2) void gemm_conv_ring_kernel(const ZsGemmConv
     const int r = wave * 32 + i * 8 + lrow;
     lseg[i] = slot ^ ((r >> 1) & 7);
     const int m = m0 + r;
-    if (m < M) { rb[i] = m / p.T_out; rt[i] = m - rb[i] * p.T_out; } else { rb[i] = -1; rt[i] = 0; }
+    conv_row_setup(p, m, M, rb[i], rt[i]);
   }
   const int chunks_per_tap = p.cin_pad / KC;
   const T* zline = reinterpret_cast<const T*>(zs_zero_line);
@@ -603,8 +619,8 @@ __global__ __launch_bounds__(RNT, 2) void gemm_conv_ring_kernel(const ZsGemmConv
 #define ZS_SET_TAP(i, ptr, inc)                                                                         \
   {                                                                                                     \
     bool ok = false; int srow = 0;                                                                      \
-    if (rb[i] >= 0) srow = conv_src_row(p.gather, p.pad_mode, p.stride, p.pad_left, p.T_in, rt[i], tap, ok); \
-    ptr = ok ? (A + (int64_t)rb[i] * p.a_batch_stride + (int64_t)srow * p.lda + lseg[i] * EPS) : (zline + lseg[i] * EPS); \
+    if (rb[i] >= 0) srow = conv_src_row(p.gather, p.pad_mode, p.stride, p.pad_left, conv_row_tin(p, rb[i]), rt[i], tap, ok); \
+    ptr = ok ? (A + (int64_t)conv_row_b(p, rb[i]) * p.a_batch_stride + (int64_t)srow * p.lda + lseg[i] * EPS) : (zline + lseg[i] * EPS); \
     inc = ok ? KC : 0;                                                                                  \
   }
   const int wr0 = wave * 16 + lrow, wr1 = wave * 16 + 8 + lrow;
@@ -1091,7 +1107,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_conv_p8m16_kernel(const ZsGemmCon
     const int r = (j >> 1) * 128 + wave * 16 + (j & 1) * 8 + lrow;
     lseg[j] = slot ^ ((r >> 1) & 7);
     const int m = m0 + r;
-    if (m < M) { rb[j] = m / p.T_out; rt[j] = m - rb[j] * p.T_out; } else { rb[j] = -1; rt[j] = 0; }
+    conv_row_setup(p, m, M, rb[j], rt[j]);
   }
   const int chunks_per_tap = p.cin_pad / KC;
   const T* zline = reinterpret_cast<const T*>(zs_zero_line);
@@ -1100,8 +1116,8 @@ __global__ __launch_bounds__(PNT, 2) void gemm_conv_p8m16_kernel(const ZsGemmCon
 #define ZS_SET_TAP(i, ptr, inc)                                                                         \
   {                                                                                                     \
     bool ok = false; int srow = 0;                                                                      \
-    if (rb[i] >= 0) srow = conv_src_row(p.gather, p.pad_mode, p.stride, p.pad_left, p.T_in, rt[i], tap, ok); \
-    ptr = ok ? (A + (int64_t)rb[i] * p.a_batch_stride + (int64_t)srow * p.lda + lseg[i] * EPS) : (zline + lseg[i] * EPS); \
+    if (rb[i] >= 0) srow = conv_src_row(p.gather, p.pad_mode, p.stride, p.pad_left, conv_row_tin(p, rb[i]), rt[i], tap, ok); \
+    ptr = ok ? (A + (int64_t)conv_row_b(p, rb[i]) * p.a_batch_stride + (int64_t)srow * p.lda + lseg[i] * EPS) : (zline + lseg[i] * EPS); \
     inc = ok ? KC : 0;                                                                                  \
   }
   const int nk = p.taps * chunks_per_tap;
@@ -1905,6 +1921,8 @@ extern "C" int zs_gemm_conv(const ZsGemmConv* p, void* stream) {
   ZS_REQUIRE(!p->colsum || (128 % p->T_out == 0 && p->colsum_col0 >= 0 && p->colsum_col0 < p->N && !p->bias && !p->pre_vec &&
                             p->act == ZS_ACT_NONE && p->groups <= 1),
              "zs_gemm_conv: colsum needs T_out (%d) to divide 128, 0 <= colsum_col0 < N and no bias / pre_vec / activation / groups", p->T_out);
+  ZS_REQUIRE(!p->lengths || (p->gather == 0 && p->B < 65536 && p->T_in < 32768 && p->pad_right >= 0 && p->colsum == nullptr),
+             "zs_gemm_conv: lengths (ragged batch) needs gather 0, B < 65536, T_in < 32768, pad_right >= 0 and no colsum");
   const int groups = p->groups > 0 ? p->groups : 1;
   const int64_t M = (int64_t)p->B * p->T_out;
   const int64_t tiles = ((M + BM - 1) / BM) * ((p->N + BN - 1) / BN);

@@ -31,6 +31,7 @@ struct GateFwdArgs {
   void* out; int64_t ldo; int out_col;
   void* gates;            // [B][T][2][4H] or null
   int B, T, H, step;
+  int dir1_forward;       // ZsGruFwd.dir1_forward: direction 1 also runs t = 0 .. T-1
 };
 
 template <typename T>
@@ -40,7 +41,7 @@ __global__ void gru_gate_fwd_kernel(const GateFwdArgs a) {
     const int d = (int)(i / ((int64_t)a.B * a.H));
     const int64_t rem = i - (int64_t)d * a.B * a.H;
     const int b = (int)(rem / a.H), j = (int)(rem - (int64_t)b * a.H);
-    const int t = d == 0 ? a.step : a.T - 1 - a.step;
+    const int t = (d == 0 || a.dir1_forward) ? a.step : a.T - 1 - a.step;
     const int H = a.H;
     const T* gi = (const T*)a.gi + ((int64_t)b * a.T + t) * a.ldgi + (int64_t)d * 3 * H;
     const float* bh = a.bhh + (int64_t)d * a.bhh_gstride;
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void rowblock_gemm_kernel(const RowGemmArgs a)
   if constexpr (GRU) {
     const GateFwdArgs& ga = a.gate;
     const int d = g, H = ga.H, j = blockIdx.x * 32 + eu;
-    e_t = d == 0 ? ga.step : ga.T - 1 - ga.step;
+    e_t = (d == 0 || ga.dir1_forward) ? ga.step : ga.T - 1 - ga.step;
     const float* bh = ga.bhh + (int64_t)d * ga.bhh_gstride;
     e_b[0] = bh[j]; e_b[1] = bh[H + j]; e_b[2] = bh[2 * H + j];
 #pragma unroll
@@ -364,6 +365,7 @@ struct GruPersistArgs {
   unsigned spin_limit;
   int B, T, H, rows_pad;
   const float* bcast_vec; int64_t bcast_ld; const int64_t* bcast_idx; int bcast_col;   // ZsGruFwd.bcast_*
+  int dir1_forward;              // ZsGruFwd.dir1_forward
 };
 
 // 16-byte agent-scope (sc1: bypasses this CU's L1) load.  Inline asm so that all loads of a sweep are in flight together
@@ -463,8 +465,9 @@ __global__ __launch_bounds__(256) void gru_persist_fwd_kernel(const GruPersistAr
     }
   }
 
+  const bool fwd_t = d == 0 || a.dir1_forward;         // this direction walks t = 0 .. T-1
   for (int s = 0; s < T_; ++s) {
-    const int t = d == 0 ? s : T_ - 1 - s;
+    const int t = fwd_t ? s : T_ - 1 - s;
     // gate inputs of this step do not depend on other workgroups: issue them before the sweep
     typename Pair<T>::raw_t q_r[2], q_z[2], q_n[2];
 #pragma unroll
@@ -681,14 +684,14 @@ __global__ __launch_bounds__(256) void gru_wide_fwd_kernel(const GruPersistArgs 
       bc_s[4 * q + i][ul] = f2bf(a.bcast_vec[a.bcast_idx[b] * a.bcast_ld + d * H + unit]);
     }
   }
+  const bool fwd_t = d == 0 || a.dir1_forward;         // this direction walks t = 0 .. T-1
   // gate inputs of step 0 (later steps: fetched one step ahead)
-  uint4 gq0 = *reinterpret_cast<const uint4*>(gi_src(tid, d == 0 ? 0 : T_ - 1)), gq1 = make_uint4(0, 0, 0, 0);
-  if (tid < 128) gq1 = *reinterpret_cast<const uint4*>(gi_src(tid + 256, d == 0 ? 0 : T_ - 1));
+  uint4 gq0 = *reinterpret_cast<const uint4*>(gi_src(tid, fwd_t ? 0 : T_ - 1)), gq1 = make_uint4(0, 0, 0, 0);
+  if (tid < 128) gq1 = *reinterpret_cast<const uint4*>(gi_src(tid + 256, fwd_t ? 0 : T_ - 1));
   gu32x4_t g4[NCHA];                                      // sweep loads of the coming step, issued right after the hand-off
   bool dead = false;
 
   for (int s = 0; s < T_; ++s) {
-    const int t = d == 0 ? s : T_ - 1 - s;
     unsigned char* const img = &himg[s & 1][0];
     f32x4_t acc[3];
 #pragma unroll
@@ -723,9 +726,9 @@ __global__ __launch_bounds__(256) void gru_wide_fwd_kernel(const GruPersistArgs 
     *gi_dst(s & 1, tid) = gq0;
     if (tid < 128) *gi_dst(s & 1, tid + 256) = gq1;
     __syncthreads();                                     // images of h_{s-1} and of this step's gate inputs are complete
-    if (s > 0) copy_out((s - 1) & 1, d == 0 ? s - 1 : T_ - s);      // the previous step's outputs leave as 16-byte stores
+    if (s > 0) copy_out((s - 1) & 1, fwd_t ? s - 1 : T_ - s);       // the previous step's outputs leave as 16-byte stores
     if (s + 1 < T_) {                                    // next step's gate inputs: in flight under this step
-      const int tn = d == 0 ? s + 1 : T_ - 2 - s;
+      const int tn = fwd_t ? s + 1 : T_ - 2 - s;
       gq0 = *reinterpret_cast<const uint4*>(gi_src(tid, tn));
       if (tid < 128) gq1 = *reinterpret_cast<const uint4*>(gi_src(tid + 256, tn));
     }
@@ -774,7 +777,7 @@ __global__ __launch_bounds__(256) void gru_wide_fwd_kernel(const GruPersistArgs 
     }
   }
   __syncthreads();
-  copy_out((T_ - 1) & 1, d == 0 ? T_ - 1 : 0);
+  copy_out((T_ - 1) & 1, fwd_t ? T_ - 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1288,6 +1291,7 @@ extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
       a.status = p->status; a.spin_limit = gru_spin_limit();
       a.B = B; a.T = T; a.H = H; a.rows_pad = wide ? nrb16 * 16 : nrb * 16 * RB;
       a.bcast_vec = p->bcast_vec; a.bcast_ld = p->bcast_ld; a.bcast_idx = p->bcast_idx; a.bcast_col = p->bcast_col;
+      a.dir1_forward = p->dir1_forward != 0;
       if (hipMemsetAsync(p->work, 0, GRU_WORK_HDR + hx_bytes, (hipStream_t)stream) != hipSuccess) {
         zs_set_error("zs_gru_fwd: memset failed");
         return ZS_ELAUNCH;
@@ -1312,13 +1316,14 @@ extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
       memset(&a, 0, sizeof(a));
       const int sp = s > 0 ? s - 1 : 0;
       const int64_t off0 = (int64_t)sp * p->ldo + p->out_col;                        // dir 0 reads h_{t-1} at row t-1
-      const int64_t off1 = (int64_t)(s > 0 ? T - s : T - 1) * p->ldo + p->out_col + H;   // dir 1 reads row t+1
+      const int64_t off1 = (int64_t)(p->dir1_forward ? sp : (s > 0 ? T - s : T - 1)) * p->ldo + p->out_col + H;   // dir 1 reads row t+1 (t-1 when it runs forward)
       a.A = outb + off0 * es; a.a_row_stride = (int64_t)T * p->ldo; a.a_gstride = off1 - off0;
       a.W = p->whh; a.ldw = p->ldw; a.w_gstride = p->w_gstride;
       a.M = B; a.N = 3 * H; a.K = H;
       GateFwdArgs& g = a.gate;
       g.gi = p->gi; g.ldgi = p->ldgi; g.gh = nullptr; g.bhh = p->bhh; g.bhh_gstride = p->bhh_gstride; g.hstate = hstate;
       g.out = p->out; g.ldo = p->ldo; g.out_col = p->out_col; g.gates = p->gates; g.B = B; g.T = T; g.H = H; g.step = s;
+      g.dir1_forward = p->dir1_forward != 0;
       dim3 grid(H / 32, (B + 16 * RB - 1) / (16 * RB), 2);
       if (p->dtype == ZS_F32) hipLaunchKernelGGL((rowblock_gemm_kernel<float, 6, 1>), grid, dim3(256), 0, (hipStream_t)stream, a);
       else hipLaunchKernelGGL((rowblock_gemm_kernel<bf16_t, 6, 1>), grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -1333,7 +1338,7 @@ extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
       memset(&g, 0, sizeof(g));
       g.dtype = p->dtype;
       const int64_t off0 = (int64_t)(s - 1) * p->ldo + p->out_col;
-      const int64_t off1 = (int64_t)(T - s) * p->ldo + p->out_col + H;
+      const int64_t off1 = (int64_t)(p->dir1_forward ? s - 1 : T - s) * p->ldo + p->out_col + H;
       g.A = outb + off0 * es; g.lda = p->ldo; g.a_batch_stride = (int64_t)T * p->ldo;
       g.a_gstride = off1 - off0;
       g.B = B; g.T_in = 1; g.T_out = 1; g.taps = 1; g.stride = 1; g.pad_left = 0; g.pad_mode = ZS_PAD_ZERO; g.gather = 0;
@@ -1348,6 +1353,7 @@ extern "C" int zs_gru_fwd(const ZsGruFwd* p, void* stream) {
     GateFwdArgs a;
     a.gi = p->gi; a.ldgi = p->ldgi; a.gh = gh; a.bhh = p->bhh; a.bhh_gstride = p->bhh_gstride; a.hstate = hstate;
     a.out = p->out; a.ldo = p->ldo; a.out_col = p->out_col; a.gates = p->gates; a.B = B; a.T = T; a.H = H; a.step = s;
+    a.dir1_forward = p->dir1_forward != 0;
     const unsigned nb = gate_blocks((int64_t)2 * B * H);
     if (p->dtype == ZS_F32) hipLaunchKernelGGL(gru_gate_fwd_kernel<float>, dim3(nb), dim3(NTG), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(gru_gate_fwd_kernel<bf16_t>, dim3(nb), dim3(NTG), 0, (hipStream_t)stream, a);

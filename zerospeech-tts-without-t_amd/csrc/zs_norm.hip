@@ -53,6 +53,10 @@ __global__ __launch_bounds__(S::NTN) void instnorm_fwd_kernel(const ZsInstNormFw
   const int tid = threadIdx.x, cg = tid % CGN, rg = tid / CGN;
   const int b = blockIdx.y, c0 = blockIdx.x * CHUNK + cg * 8;
   const bool cvalid = c0 < p.C;
+  // ragged batch: this sample's own length (p.T / p.T_res stay the row strides); same row -> thread mapping and reduction order
+  // as a launch with T = Tb, so a sample's result does not depend on what it is batched with
+  const int Tb = p.lengths ? p.lengths[b] : p.T;
+  const int Tres_b = p.res_lengths ? p.res_lengths[b] : p.T_res;
   const T* x = (const T*)p.x;
   Raw8<T> v[RPT];            // rows stay as loaded (bf16: 4 registers per 8 values instead of 8) between the passes: occupancy
   float s[8];
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(S::NTN) void instnorm_fwd_kernel(const ZsInstNormFw
   for (int i = 0; i < RPT; ++i) {
     const int t = rg + RG * i;
     rr0[i].zero();
-    if (cvalid && t < p.T) {
+    if (cvalid && t < Tb) {
       if (p.res_mode == ZS_RES_IDENTITY) rr0[i].ld(res + ((int64_t)b * p.T + t) * p.ldres + c0);
       else if (p.res_mode == ZS_RES_UPSAMPLE2) rr0[i].ld(res + ((int64_t)b * p.T_res + (t >> 1)) * p.ldres + c0);
       else if (p.res_mode == ZS_RES_AVGPOOL2) {
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(S::NTN) void instnorm_fwd_kernel(const ZsInstNormFw
   for (int i = 0; i < RPT; ++i) {
     const int t = rg + RG * i;
     v[i].zero();
-    if (cvalid && t < p.T) v[i].ld(x + ((int64_t)b * p.T + t) * p.ldx + c0);
+    if (cvalid && t < Tb) v[i].ld(x + ((int64_t)b * p.T + t) * p.ldx + c0);
   }
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
@@ -89,13 +93,13 @@ __global__ __launch_bounds__(S::NTN) void instnorm_fwd_kernel(const ZsInstNormFw
   }
   colreduce<S>(s, red, tot, cg, rg, tid);
   float mean[8], q[8];
-  const float invT = 1.f / (float)p.T;
+  const float invT = 1.f / (float)Tb;
 #pragma unroll
   for (int k = 0; k < 8; ++k) { mean[k] = s[k] * invT; q[k] = 0.f; }
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
     const int t = rg + RG * i;
-    if (t < p.T) {
+    if (t < Tb) {
       float f[8]; v[i].cvt(f);
 #pragma unroll
       for (int k = 0; k < 8; ++k) { const float d = f[k] - mean[k]; q[k] += d * d; }
@@ -124,6 +128,13 @@ __global__ __launch_bounds__(S::NTN) void instnorm_fwd_kernel(const ZsInstNormFw
     if (t >= p.T) continue;
     const int64_t row = (int64_t)b * p.T + t;
     float o[8], f[8];
+    if (t >= Tb) {                                 // ragged batch: rows past the sample's length are zeros
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = 0.f;
+      store8<T>((T*)p.out + row * p.ldo + c0, o);
+      if (p.out2) store8<T>((T*)p.out2 + row * p.ldo2 + c0, o);
+      continue;
+    }
     v[i].cvt(f);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -137,7 +148,7 @@ __global__ __launch_bounds__(S::NTN) void instnorm_fwd_kernel(const ZsInstNormFw
     } else if (p.res_mode == ZS_RES_AVGPOOL2) {
       float r0[8], r1[8]; rr0[i].cvt(r0);
       int t1 = 2 * t + 1; bool have = true;
-      if (t1 >= p.T_res) { if (p.res_pad_mode == ZS_PAD_REFLECT) t1 = p.T_res - 2; else have = false; }
+      if (t1 >= Tres_b) { if (p.res_pad_mode == ZS_PAD_REFLECT) t1 = Tres_b - 2; else have = false; }
       if (have) load8<T>(res + ((int64_t)b * p.T_res + t1) * p.ldres + c0, r1);
       else {
 #pragma unroll

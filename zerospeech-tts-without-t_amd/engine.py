@@ -54,11 +54,25 @@ class EncoderEngine(object):
             self.gru.pack()
 
     # ------------------------------------------------------------------------------------------
-    def forward(self, x, training, noise=None, noise_kind=2, seed=0, drop_masks=None, seed_ptr=None):
+    def forward(self, x, training, noise=None, noise_kind=2, seed=0, drop_masks=None, seed_ptr=None, lengths=None):
         """x: fp32 [B, T, c_in] contiguous on device.  Returns (bits Act [B,T',E] (T dtype, feeds the decoder),
-        bits_f32 [B,T',E], logits_f32 [B,T',ld]).  noise: fp32 [B,T',E,2] (Gumbel if noise_kind 0, uniform if 1)."""
+        bits_f32 [B,T',E], logits_f32 [B,T',ld]).  noise: fp32 [B,T',E,2] (Gumbel if noise_kind 0, uniform if 1).
+        lengths: host int sequence [B], frames per sample (ragged batch, inference only): sample b is computed exactly as if it ran
+        alone with T = lengths[b] (padding, InstanceNorm statistics and the reverse GRU at its own end); its first
+        ceil(ceil(ceil(lengths[b]/2)/2)/2) output rows are valid, the rest is garbage."""
         c, ns = self.ctx, self.ns
         B, T, F = x.shape
+        Ls = [None] * 4
+        if lengths is not None:
+            if training:
+                raise L.ZsError('EncoderEngine: ragged batches are an inference feature')
+            l0 = torch.as_tensor(lengths, dtype=torch.int32).reshape(-1)
+            if l0.numel() != B or int(l0.max()) > T or int(l0.min()) < 9:
+                raise L.ZsError('EncoderEngine: lengths must be %d values in [9, %d]' % (B, T))     # MIN_LEN (convert.py:36)
+            l1 = (l0 + 1) // 2; l2 = (l1 + 1) // 2; l3 = (l2 + 1) // 2
+            self.last_lengths = l3
+            ld = torch.stack([l0, l1, l2, l3]).to(c.device, non_blocking=True)
+            Ls = [ld[i] for i in range(4)]
         assert F == self.c_in and x.dtype == torch.float32 and x.is_contiguous()
         st = c.stream
         c1, c2, H, E = self.c1, self.c2, self.H, self.E
@@ -79,23 +93,23 @@ class EncoderEngine(object):
             sts = fork_side(c.device)
             for i, l in enumerate(self.conv1s):                                                               # :441-444
                 with torch.cuda.stream(sts[i % len(sts)]):
-                    l.fwd(xin, out=cat.sub(i * c1, c1), act=LRELU, slope=ns)
+                    l.fwd(xin, out=cat.sub(i * c1, c1), act=LRELU, slope=ns, lengths=Ls[0])
             join_side(c.device)
         else:
             for i, l in enumerate(self.conv1s):
-                l.fwd(xin, out=cat.sub(i * c1, c1), act=LRELU, slope=ns)
+                l.fwd(xin, out=cat.sub(i * c1, c1), act=LRELU, slope=ns, lengths=Ls[0])
         y2 = c.act('e_y2' + tag, B, T, c2)
         self.conv2.fwd(cat, out=y2, act=LRELU, slope=ns)                                                      # :447
         a = c.act('e_a0' + tag, B, T, c2)
-        st0 = self._in(y2, a, tp, 0, res_mode=L.ZS_RES_NONE)
+        st0 = self._in(y2, a, tp, 0, res_mode=L.ZS_RES_NONE, lengths=Ls[0])
         tp.update(xin=xin, cat=cat, y2=y2, a0=a, st0=st0, blocks=[], dense=[])
         for i, (la, lb) in enumerate(self.convs):                                                            # :448-450
             ya = c.act('e_ya%d' % i + tag, B, Ts[i], c2)
-            la.fwd(a, out=ya, act=LRELU, slope=ns)
+            la.fwd(a, out=ya, act=LRELU, slope=ns, lengths=Ls[i])
             yb = c.act('e_yb%d' % i + tag, B, Ts[i + 1], c2)
-            lb.fwd(ya, out=yb, act=LRELU, slope=ns)
+            lb.fwd(ya, out=yb, act=LRELU, slope=ns, lengths=Ls[i])
             an = c.act('e_a%d' % (i + 1) + tag, B, Ts[i + 1], c2)
-            stt = self._in(yb, an, tp, 1 + i, res_mode=L.ZS_RES_AVGPOOL2, res=a)
+            stt = self._in(yb, an, tp, 1 + i, res_mode=L.ZS_RES_AVGPOOL2, res=a, lengths=Ls[i + 1], res_lengths=Ls[i])
             tp['blocks'].append((a, ya, yb, stt))
             a = an
         cat2 = c.act('e_cat2' + tag, B, T4, c2 + 2 * H)
@@ -105,12 +119,12 @@ class EncoderEngine(object):
             d2 = c.act('e_d2%d' % j + tag, B, T4, c2)
             lb.fwd(d1, out=d2, act=LRELU, slope=ns)
             out = c.act('e_do%d' % j + tag, B, T4, c2) if j == 0 else Act(cat2.t, B, T4, c2, cat2.ld, 0, rup(c2, 32))
-            stt = self._in(d2, out, tp, 4 + j, res_mode=L.ZS_RES_IDENTITY, res=a)
+            stt = self._in(d2, out, tp, 4 + j, res_mode=L.ZS_RES_IDENTITY, res=a, lengths=Ls[3])
             tp['dense'].append((a, d1, d2, stt))
             a = out
         gi = c.act('e_gi' + tag, B, T4, 6 * H)
         gates = c.raw('e_gates' + tag, B * T4 * 8 * H, c.tdt) if training else None
-        self.gru.fwd(a, cat2, c2, gi, gates)                                                                 # :454-455
+        self.gru.fwd(a, cat2, c2, gi, gates, lengths=Ls[3])                                                 # :454-455
         logits = c.act('e_logits' + tag, B, T4, 2 * E, dtype=torch.float32)
         self.linear.fwd(cat2, out=logits, out_f32=True)                                                      # :475
         bits = c.act('e_bits' + tag, B, T4, E)
@@ -123,7 +137,7 @@ class EncoderEngine(object):
         self.tape = tp
         return bits, bits_f32[:B * T4 * E].view(B, T4, E), logits
 
-    def _in(self, x, out, tp, k, res_mode, res=None):
+    def _in(self, x, out, tp, k, res_mode, res=None, lengths=None, res_lengths=None):
         """InstanceNorm + Dropout + residual (model/model.py:421-427, 434-437)."""
         c = self.ctx
         B, T, C = x.B, x.T, x.ld
@@ -136,7 +150,8 @@ class EncoderEngine(object):
                mean=L.ptr(mean), rstd=L.ptr(rstd), B=B, T=T, C=C, eps=EPS_IN, drop_p=tp['dp'], seed=tp['seed'],
                stream_id=k + 1, mask=L.ptr(m), mask_ld=(m.shape[-1] if m is not None else 0), res_mode=res_mode,
                res=(res.ptr() if res is not None else None), ldres=(res.ld if res is not None else 0),
-               T_res=(res.T if res is not None else 0), res_pad_mode=self.pad_mode, seed_ptr=tp.get('seed_ptr'))
+               T_res=(res.T if res is not None else 0), res_pad_mode=self.pad_mode, seed_ptr=tp.get('seed_ptr'),
+               lengths=L.ptr(lengths), res_lengths=L.ptr(res_lengths))
         return (mean, rstd, k)
 
     def _in_bwd(self, dout, x, stt, dz, tp):
@@ -251,10 +266,21 @@ class DecoderEngine(object):
                 l.pack()
             self.gru.pack()
 
-    def forward(self, bits, cidx, training):
-        """bits: Act [B,T',E] (T dtype, zero padded); cidx int64 [B].  Returns x_dec Act fp32 [B, 8T', F]."""
+    def forward(self, bits, cidx, training, lengths=None):
+        """bits: Act [B,T',E] (T dtype, zero padded); cidx int64 [B].  Returns x_dec Act fp32 [B, 8T', F].
+        lengths: host int sequence [B], encoded frames per sample (ragged batch, inference only): sample b is computed as if it
+        ran alone with T' = lengths[b]; its first 8 * lengths[b] output rows are valid."""
         c, ns, ch = self.ctx, self.ns, self.ch
         B, T0 = bits.B, bits.T
+        Ls = [None] * 4
+        if lengths is not None:
+            if training:
+                raise L.ZsError('DecoderEngine: ragged batches are an inference feature')
+            l0 = torch.as_tensor(lengths, dtype=torch.int32).reshape(-1)
+            if l0.numel() != B or int(l0.max()) > T0 or int(l0.min()) < 2:
+                raise L.ZsError('DecoderEngine: lengths must be %d values in [2, %d]' % (B, T0))    # reflect pad 1 of conv k3 needs 2 rows
+            ld = torch.stack([l0, 2 * l0, 4 * l0, 8 * l0]).to(c.device, non_blocking=True)
+            Ls = [ld[i] for i in range(4)]
         tag = '_%d_%d_%d' % (self.uid, B, T0)
         st = c.stream
         emb = self.emb
@@ -266,13 +292,13 @@ class DecoderEngine(object):
         for i, (la, lb) in enumerate(self.convs):                                                        # :317-331
             ya = c.act('d_ya%d' % i + tag, B, T, 2 * ch) if training else None
             s = c.act('d_s%d' % i + tag, B, 2 * T, ch)
-            la.fwd(xe, out=ya, act=LRELU, slope=ns, out2=s, vec2=emb[i], idx=cidx, store_mode2=L.ZS_STORE_SPLIT2)
+            la.fwd(xe, out=ya, act=LRELU, slope=ns, out2=s, vec2=emb[i], idx=cidx, store_mode2=L.ZS_STORE_SPLIT2, lengths=Ls[i])
             yb = c.act('d_yb%d' % i + tag, B, 2 * T, ch)
-            lb.fwd(s, out=yb, act=LRELU, slope=ns)
+            lb.fwd(s, out=yb, act=LRELU, slope=ns, lengths=Ls[i + 1])
             xn = c.act('d_x%d' % (i + 1) + tag, B, 2 * T, ch)
             xen = c.act('d_xe%d' % (i + 1) + tag, B, 2 * T, ch)
             nxt = emb[i + 1] if i < 2 else emb[3]                                                        # emb2, emb3, then emb4 (:350)
-            stt = self._in(yb, xn, xen, nxt, cidx, L.ZS_RES_UPSAMPLE2, x, training, 'c%d' % i)
+            stt = self._in(yb, xn, xen, nxt, cidx, L.ZS_RES_UPSAMPLE2, x, training, 'c%d' % i, lengths=Ls[i + 1])
             tp['blocks'].append((x, xe, ya, s, yb, stt, T))
             x, xe, T = xn, xen, 2 * T
         cat3 = c.act('d_cat3' + tag, B, T, 3 * ch)
@@ -284,14 +310,14 @@ class DecoderEngine(object):
             lb.fwd(y1e, out=y2, act=LRELU, slope=ns)
             xn = c.act('d_dx%d' % j + tag, B, T, ch) if j == 0 else Act(cat3.t, B, T, ch, cat3.ld, 0, ch)
             xen = c.act('d_dxe%d' % j + tag, B, T, ch)
-            stt = self._in(y2, xn, xen, emb[3] if j == 0 else emb[4], cidx, L.ZS_RES_IDENTITY, x, training, 'd%d' % j)
+            stt = self._in(y2, xn, xen, emb[3] if j == 0 else emb[4], cidx, L.ZS_RES_IDENTITY, x, training, 'd%d' % j, lengths=Ls[3])
             tp['dense'].append((x, xe, y1, y1e, y2, stt))
             x, xe = xn, xen
         H = ch // 2
         gi = c.act('d_gi' + tag, B, T, 6 * H)
         gates = c.raw('d_gates' + tag, B * T * 8 * H, c.tdt) if training else None
         # :352-356, and append_emb (:357) rides on the recurrence's stores (third block of cat3 = emb5[c_b] at every t)
-        self.gru.fwd(xe, cat3, ch, gi, gates, bcast=(emb[4], cidx, 2 * ch))
+        self.gru.fwd(xe, cat3, ch, gi, gates, bcast=(emb[4], cidx, 2 * ch), lengths=Ls[3])
         h5 = c.act('d_h5' + tag, B, T, ch)
         self.dense5.fwd(cat3, out=h5, act=LRELU, slope=ns)                                                # :358-359
         return self._fwd_tail(c, tp, h5, cat3, gates, xe, T, tag, B)
@@ -303,7 +329,7 @@ class DecoderEngine(object):
         self.tape = tp
         return xdec
 
-    def _in(self, x, out, out2, vec2, cidx, res_mode, res, training, key):
+    def _in(self, x, out, out2, vec2, cidx, res_mode, res, training, key, lengths=None):
         c = self.ctx
         B, T, C = x.B, x.T, x.ld
         mean = rstd = None
@@ -313,7 +339,7 @@ class DecoderEngine(object):
         L.call('zs_instnorm_fwd', 'ZsInstNormFwd', c.stream, dtype=c.dt, x=x.ptr(), ldx=x.ld, out=out.ptr(), ldo=out.ld,
                out2=out2.ptr(), ldo2=out2.ld, vec2=L.ptr(vec2), vec2_ld=vec2.shape[1], vec2_cols=vec2.shape[1], idx=L.ptr(cidx),
                mean=L.ptr(mean), rstd=L.ptr(rstd), B=B, T=T, C=C, eps=EPS_IN, drop_p=0.0, res_mode=res_mode, res=res.ptr(),
-               ldres=res.ld, T_res=res.T, res_pad_mode=self.pad_mode)
+               ldres=res.ld, T_res=res.T, res_pad_mode=self.pad_mode, lengths=L.ptr(lengths))
         return (mean, rstd)
 
     def _in_bwd(self, dout, x, stt, dz):

@@ -132,17 +132,6 @@ def check_status(device):
                         (' and '.join(n for b, n in ((1, 'forward'), (2, 'BPTT')) if v & b), v))
 
 
-_LANE = {}
-
-
-def lane_stream(device, i):
-    """Extra stream i >= 1 of a buffer set (see Ctx.lane; convert.encode_batch runs its length groups on several)."""
-    key = (device.type, device.index, i)
-    if key not in _LANE:
-        _LANE[key] = torch.cuda.Stream(device)
-    return _LANE[key]
-
-
 _COPY = {}
 
 
@@ -170,7 +159,6 @@ class Ctx(object):
         self.kc = 128 // self.es
         self._bufs = {}
         self._ws = None
-        self.lane = ''               # name of the current buffer set: launches on different streams must not share scratch buffers
         # True: a layer's weight gradients always go to the same side stream (stage 2: several passes of a step accumulate into
         # one gradient buffer, and stream order makes that sum deterministic)
         self.pin_wgrad_streams = False
@@ -186,7 +174,7 @@ class Ctx(object):
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def raw(self, name, n, dtype, zero=True):
-        key = (self.lane, name, n, dtype)
+        key = (name, n, dtype)
         t = self._bufs.get(key)
         if t is None:
             t = torch.zeros(n + SLACK, dtype=dtype, device=self.device)
@@ -264,8 +252,9 @@ class ConvLayer(object):
         return (T_in + self.pad_l + self.pad_r - self.k) // self.stride + 1
 
     def fwd(self, A, out=None, act=L.ZS_ACT_NONE, slope=0.0, out_f32=False, out_cols=None, store_mode=L.ZS_STORE_ROWS,
-            out2=None, vec2=None, idx=None, store_mode2=L.ZS_STORE_ROWS, out2_cols=None, pre_vec=None, bias=True):
-        """A: Act [B,T_in,Cin] -> out Act [B,T_out,Cout] (or pixel-shuffled).  Returns T_out."""
+            out2=None, vec2=None, idx=None, store_mode2=L.ZS_STORE_ROWS, out2_cols=None, pre_vec=None, bias=True, lengths=None):
+        """A: Act [B,T_in,Cin] -> out Act [B,T_out,Cout] (or pixel-shuffled).  Returns T_out.
+        lengths: int32 device tensor [B], valid input rows per sample (ragged batch, see ZsGemmConv.lengths)."""
         c = self.ctx
         T_out = self.t_out(A.T)
         kw = dict(dtype=c.dt, A=A.ptr(), lda=A.ld, a_batch_stride=A.T * A.ld, B=A.B, T_in=A.T, T_out=T_out, taps=self.k,
@@ -274,6 +263,8 @@ class ConvLayer(object):
                   slope=slope, groups=1)
         if pre_vec is not None:
             kw.update(pre_vec=L.ptr(pre_vec), pre_vec_ld=pre_vec.shape[1], vec_idx=L.ptr(idx))
+        if lengths is not None and self.k > 1:             # (a 1-tap layer is row-wise: rows past a length stay unread garbage)
+            kw.update(lengths=L.ptr(lengths), pad_right=self.pad_r)
         if out is not None:
             kw.update(out=out.ptr(), ldc=out.ld, out_f32=int(out_f32), store_mode=store_mode,
                       out_cols=out_cols if out_cols is not None else (min(out.cols, rup(self.Cout, 32)) if store_mode == L.ZS_STORE_ROWS else self.Cout // 2))
@@ -442,15 +433,23 @@ class GruLayer(object):
         n = L.lib().zs_gru_work_bytes(B, self.H)
         return self.ctx.f32('gru_work_%s' % self.name, (n + 3) // 4)
 
-    def fwd(self, X, out, out_col, gi, gates, bcast=None):
+    def fwd(self, X, out, out_col, gi, gates, bcast=None, lengths=None):
         """X: Act [B,T,Cin]; out: Act whose columns [out_col, out_col+2H) receive h (fwd ++ bwd);
         gi: Act [B,T,6H] scratch; gates: raw tensor (T dtype, B*T*2*4H) or None.
-        bcast = (vec fp32 [n, >= 2H], idx int64 [B], col): out[b, t, col:col+2H] = vec[idx[b], :2H] for every t (append_emb)."""
+        bcast = (vec fp32 [n, >= 2H], idx int64 [B], col): out[b, t, col:col+2H] = vec[idx[b], :2H] for every t (append_emb).
+        lengths: int32 device tensor [B] (ragged batch, inference): the reverse direction of sample b starts at ITS last row --
+        its gate inputs are reversed per sample over its own length, both directions run forward in time (ZsGruFwd.dir1_forward),
+        and its outputs are reversed back.  Rows past a sample's length hold garbage."""
         c, H = self.ctx, self.H
+        if lengths is not None and gates is not None:
+            raise L.ZsError('GruLayer.fwd: ragged batches are an inference feature (no tape)')
         L.call('zs_gemm_conv', 'ZsGemmConv', c.stream, dtype=c.dt, A=X.ptr(), lda=X.ld, a_batch_stride=X.T * X.ld, B=X.B,
                T_in=X.T, T_out=X.T, taps=1, stride=1, pad_left=0, pad_mode=L.ZS_PAD_ZERO, gather=0, cin_pad=self.cin_pad,
                W=L.ptr(self.wih_f), ldw=self.ih_ldw, N=6 * H, n_pad=self.ih_npad, bias=L.ptr(self.bih), act=L.ZS_ACT_NONE,
                out=gi.ptr(), ldc=gi.ld, out_cols=min(gi.cols, rup(6 * H, 32)), groups=1)
+        if lengths is not None:
+            L.call('zs_rows_reverse', 'ZsRowsReverse', c.stream, dtype=c.dt, x=gi.ptr(), ld=gi.ld, col0=3 * H, cols=3 * H, B=X.B, T=X.T,
+                   lengths=L.ptr(lengths))
         work = self._work(X.B)
         L.call('zs_gru_fwd', 'ZsGruFwd', c.stream, dtype=c.dt, B=X.B, T=X.T, H=H, gi=gi.ptr(), ldgi=gi.ld,
                whh=L.ptr(self.whh_f), ldw=self.hh_ldw, n_pad=self.hh_npad, w_gstride=self.hh_npad * self.hh_ldw,
@@ -458,7 +457,11 @@ class GruLayer(object):
                gates=L.ptr(gates) if gates is not None else None, work=L.ptr(work), work_bytes=work.numel() * 4,
                whh_interleaved=int(self.fast), status=L.ptr(c.status),
                bcast_vec=(L.ptr(bcast[0]) if bcast else None), bcast_ld=(bcast[0].shape[1] if bcast else 0),
-               bcast_idx=(L.ptr(bcast[1]) if bcast else None), bcast_col=(bcast[2] if bcast else 0))
+               bcast_idx=(L.ptr(bcast[1]) if bcast else None), bcast_col=(bcast[2] if bcast else 0),
+               dir1_forward=int(lengths is not None))
+        if lengths is not None:
+            L.call('zs_rows_reverse', 'ZsRowsReverse', c.stream, dtype=c.dt, x=out.ptr(), ld=out.ld, col0=out_col + H, cols=H, B=X.B, T=X.T,
+                   lengths=L.ptr(lengths))
 
     def check(self, B):
         """Test hook: raise if the last persistent pass over this layer's work buffer timed out (synchronises)."""

@@ -137,10 +137,13 @@ class Encoder(ZsModule):
     def _make_engine(self, ctx, P, G):
         return EncoderEngine(ctx, P, G, self.c_in, self.c_h1, self.c_h2, self.c_h3, self.enc_size, self.ns, self.dp, self.seg_len)
 
-    def forward(self, x, U=None, G=None, drop_masks=None, seed=None):
+    def forward(self, x, U=None, G=None, drop_masks=None, seed=None, lengths=None):
         """x [B, c_in, T] -> (enc_act [B, E, T/8], enc [B, 2E, T/8]).  The Gumbel-softmax draws noise in
         eval mode too (reference behaviour, model/model.py:95-98): pass U (uniform) or G (Gumbel) to make
-        it reproducible; otherwise a counter-hash stream seeded from torch's RNG is used."""
+        it reproducible; otherwise a counter-hash stream seeded from torch's RNG is used.
+        lengths (eval only): frames per sample of a ragged batch padded to T -- every sample is computed exactly as if it were
+        forwarded alone with its own length (the reference forwards such fragments one at a time, convert.py:154-165); the
+        first ceil(lengths[b] / 8) output frames of sample b are valid."""
         eng = self._engine()
         xb = x.detach().permute(0, 2, 1).contiguous().float()
         noise, kind = None, 2
@@ -153,7 +156,7 @@ class Encoder(ZsModule):
         masks = None
         if drop_masks is not None:
             masks = [m.to(xb.device, torch.uint8).contiguous() if m is not None else None for m in drop_masks]
-        bits, bits_f32, logits = eng.forward(xb, self.training, noise=noise, noise_kind=kind, seed=seed, drop_masks=masks)
+        bits, bits_f32, logits = eng.forward(xb, self.training, noise=noise, noise_kind=kind, seed=seed, drop_masks=masks, lengths=lengths)
         self._last_bits = bits
         enc_act = bits_f32.permute(0, 2, 1).clone()
         enc = logits.valid().permute(0, 2, 1).clone()
@@ -193,8 +196,9 @@ class Decoder(ZsModule):
     def emb_grad_views(self):
         return [self.grad_view('emb%d.weight' % i) for i in range(1, 6)]
 
-    def forward(self, x, c):
-        """x: enc_act [B, c_in, T'] (fp32);  c: int64 [B]  ->  [B, c_out, 8T']."""
+    def forward(self, x, c, lengths=None):
+        """x: enc_act [B, c_in, T'] (fp32);  c: int64 [B]  ->  [B, c_out, 8T'].
+        lengths (eval only): encoded frames per sample of a ragged batch; the first 8 * lengths[b] output frames are valid."""
         eng = self._engine()
         ctx = eng.ctx
         xb = x.detach().permute(0, 2, 1).contiguous().float()
@@ -203,7 +207,7 @@ class Decoder(ZsModule):
         L.call('zs_cast_rows', 'ZsCastRows', ctx.stream, dtype=ctx.dt, src=L.ptr(xb), ld_src=E, src_f32=1, dst=bits.ptr(),
                ld_dst=bits.ld, dst_f32=0, col_off=0, rows=B * T0, cols=E, fill_cols=bits.ld, act=L.ZS_ACT_NONE)
         cidx = c.detach().to(xb.device, torch.int64).contiguous()
-        xdec = eng.forward(bits, cidx, self.training)
+        xdec = eng.forward(bits, cidx, self.training, lengths=lengths)
         return xdec.valid().permute(0, 2, 1).clone()
 
 
