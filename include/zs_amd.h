@@ -454,6 +454,12 @@ int zs_pre_spectrogram(const ZsPreSpec* p, void* stream);
 int zs_pre_mel(const float* amp, const float* basis, float* mel, int64_t rows, int32_t n_mels, float ref_db, float max_db, void* stream);
 int zs_gl_denormalize(const float* mag_norm, float* mag_amp, int64_t n, void* stream);
 int zs_gl_deemphasis(float* wav, int64_t wav_ld, const int32_t* lengths, int32_t n_utt, float coef, void* stream);
+/* zs_gl_frame_mse: the frame statistics of librosa.effects.trim (convert.py:61; librosa's rms on the centred, reflect-padded
+ * signal): mse[u][f] = mean_{i < frame_length} y_u[reflect(f*hop + i - frame_length/2)]^2, f <= L_u / hop, L_u = 200 *
+ * (lengths[u] - 1) samples of wav row u (needs L_u > frame_length / 2), accumulated in double.  The caller thresholds at
+ * top_db below the maximum and slices: only these few hundred values per utterance are examined on the host. */
+int zs_gl_frame_mse(const float* wav, int64_t wav_ld, const int32_t* lengths, int32_t n_utt, int32_t frame_length, int32_t hop,
+                    double* mse, int64_t mse_ld, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------

@@ -171,6 +171,52 @@ def test_griffin_lim_audio_700_frames_vs_oracle(cv, n_iter):
     assert err < 1e-3, err
 
 
+def test_griffin_lim_audio_at_hp_n_iter_300_vs_oracle(cv):
+    """hp.n_iter = 300 (hps/hps.py:31), the product setting: the AUDIO of the GPU Griffin-Lim against the oracle's after all 300
+    iterations, 350 speech-like frames, at the north_star tolerance (1e-3 of the waveform scale)."""
+    import zs_oracle as O
+    y = _speechlike(350, 7)
+    S = np.abs(O.stft(y)).astype(np.float32)
+    w_gpu = cv.griffin_lim(S, n_iter=300)
+    w_ref = O.griffin_lim(S, n_iter=300)
+    assert w_gpu.shape == w_ref.shape == (200 * 349,)
+    err = np.abs(w_gpu - w_ref).max() / np.abs(w_ref).max()
+    rms = np.sqrt(np.mean((w_gpu - w_ref) ** 2)) / np.sqrt(np.mean(w_ref ** 2))
+    print('GL 300 iterations, 350 frames: max err %.3g of scale, rms err %.3g' % (err, rms))
+    assert err < 1e-3, err
+
+
+def test_trim_statistics_on_the_device_equal_the_host_trim(cv):
+    """zs_gl_frame_mse + trim_bounds (librosa.effects.trim restated, convert.py:61) against the host-side trim() on signals with
+    silent ends, lengths that are and are not multiples of the hop, and an all-quiet signal; through spectrogram2wav_batch the
+    two paths return identical samples."""
+    from zs_amd import _lib as L
+    dev = torch.device('cuda:0')
+    rng = np.random.RandomState(4)
+    Ts = [700, 351, 40, 8, 123]
+    n_max = 200 * (max(Ts) - 1)
+    x = np.zeros((len(Ts), n_max), dtype=np.float32)
+    for i, T in enumerate(Ts):
+        n = 200 * (T - 1)
+        y = (rng.randn(n) * 0.1).astype(np.float32)
+        lo, hi = int(0.13 * n), int(0.81 * n)
+        y[:lo] *= 1e-5; y[hi:] *= 1e-5                          # "silence" 100 dB down at both ends
+        x[i, :n] = y
+    x[3, :] *= 1e-7                                             # all quiet: everything is within 60 dB of its own maximum
+    w = torch.from_numpy(x).to(dev)
+    lens = torch.tensor(Ts, dtype=torch.int32, device=dev)
+    nf = 1 + n_max // cv.TRIM_HOP
+    mse = torch.zeros(len(Ts), nf, dtype=torch.float64, device=dev)
+    L.check(L.lib().zs_gl_frame_mse(L.ptr(w), n_max, L.ptr(lens), len(Ts), cv.TRIM_FRAME, cv.TRIM_HOP, L.ptr(mse), nf,
+                                    torch.cuda.current_stream().cuda_stream), 'zs_gl_frame_mse')
+    m = mse.cpu().numpy()
+    for i, T in enumerate(Ts):
+        n = 200 * (T - 1)
+        _, (a, b) = cv.trim(x[i, :n])
+        assert cv.trim_bounds(m[i, :1 + n // cv.TRIM_HOP], n) == (a, b), (T, cv.trim_bounds(m[i, :1 + n // cv.TRIM_HOP], n), (a, b))
+        assert 0 <= a < b <= n
+
+
 def test_griffin_lim_300_iterations_converges_like_oracle(cv):
     """n_iter = 300 (hps/hps.py:31): compare spectral convergence |STFT(x)| vs target of GPU and oracle results."""
     import zs_oracle as O

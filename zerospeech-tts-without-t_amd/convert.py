@@ -112,6 +112,19 @@ def trim(wav, top_db=60, frame_length=2048, hop_length=512):
     return y[start:end], (start, end)
 
 
+TRIM_FRAME, TRIM_HOP = 2048, 512        # librosa.effects.trim defaults
+
+
+def trim_bounds(mse, n, top_db=60, hop_length=TRIM_HOP):
+    """(start, stop) of librosa.effects.trim given the frame mean squares (see trim())."""
+    mse = np.asarray(mse, dtype=np.float64)
+    db = 10.0 * np.log10(np.maximum(1e-10, mse)) - 10.0 * np.log10(np.maximum(1e-10, np.max(mse)))
+    nz = np.flatnonzero(db > -top_db)
+    if nz.size == 0:
+        return 0, 0
+    return int(nz[0]) * hop_length, min(n, (int(nz[-1]) + 1) * hop_length)
+
+
 def spectrogram2wav_batch(mags_tf, n_iter=None, do_trim=True):
     """Batched spectrogram2wav (convert.py:55-62): list of [T_i, 513] normalised magnitudes -> list of float32 wavs.
     One padded host buffer, one H2D copy, one de-normalisation launch, one zs_griffin_lim call, one de-emphasis launch, one
@@ -134,12 +147,25 @@ def spectrogram2wav_batch(mags_tf, n_iter=None, do_trim=True):
     wav, lengths, lens = griffin_lim_batch(None, n_iter=n_iter, device=dev, mag_padded=(amp, lens))
     L.check(L.lib().zs_gl_deemphasis(L.ptr(wav), wav.shape[1], L.ptr(lengths), len(lens), float(hp.preemphasis), st),
             'zs_gl_deemphasis')                               # signal.lfilter([1], [1, -0.97], wav)
-    w = wav.cpu().numpy()
+    mse_h = None
+    if do_trim and min(lens) > 6:                            # frame statistics of librosa.effects.trim on the device (convert.py:61)
+        nf = 1 + wav.shape[1] // TRIM_HOP
+        mse = torch.zeros(len(lens), nf, dtype=torch.float64, device=dev)
+        L.check(L.lib().zs_gl_frame_mse(L.ptr(wav), wav.shape[1], L.ptr(lengths), len(lens), TRIM_FRAME, TRIM_HOP, L.ptr(mse), nf, st),
+                'zs_gl_frame_mse')
+        mse_h = _to_host(mse)
+    w_h = _to_host(wav)
+    torch.cuda.current_stream(dev).synchronize()
+    w = w_h.numpy()
     out = []
     for i, T in enumerate(lens):
         y = w[i, :200 * (T - 1)]
         if do_trim:
-            y, _ = trim(y)
+            if mse_h is not None:
+                a, b = trim_bounds(mse_h[i, :1 + len(y) // TRIM_HOP].numpy(), len(y))
+                y = y[a:b]
+            else:
+                y, _ = trim(y)
         out.append(np.asarray(y, dtype=np.float32))
     return out
 
@@ -254,13 +280,49 @@ def encode(src_speaker_spec, trainer, seg_len, s_speaker=None, utt_id=None, resu
         return encodings
 
 
+_POOL = None
+
+
+def _pool():
+    """A few host threads for the memcpy-bound staging of batches into pinned memory (torch releases the GIL inside copy_)."""
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=max(1, min(8, (os.cpu_count() or 2) // 2)))
+    return _POOL
+
+
+def _stage_rows(arrays, dev):
+    """list of [T_i, C] arrays on the host -> (device fp32 tensor [sum T_i + 1, C] whose LAST row is zeros, row offsets).
+    One pass over the bytes into a pinned buffer (torch's caching host allocator recycles it between calls), several threads,
+    then ONE asynchronous H2D copy at the link rate -- a pageable .to(device) of the same bytes is 3-4 x slower."""
+    C = int(arrays[0].shape[1])
+    offs = np.concatenate(([0], np.cumsum([int(a.shape[0]) for a in arrays]))).astype(np.int64)
+    total = int(offs[-1])
+    host = torch.empty(total + 1, C, dtype=torch.float32, pin_memory=True)
+    host[total].zero_()
+
+    def put(i):
+        host[offs[i]:offs[i + 1]].copy_(torch.from_numpy(np.ascontiguousarray(arrays[i], dtype=np.float32)))
+    list(_pool().map(put, range(len(arrays))))
+    return host.to(dev, non_blocking=True), offs
+
+
+def _to_host(t):
+    """Device tensor -> numpy array backed by pinned memory (asynchronous D2H; the caller synchronises once for all of them)."""
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t, non_blocking=True)
+    return h
+
+
 def encode_batch(specs, trainer, seg_len, decode_speakers=None, noise_fn=None, max_batch=256, to_host=True):
-    """Batched encode()/convert() for many utterances: the same fragments the reference would send through the
-    network one by one (convert.py:151-165) are grouped by length and run as batches on the GPU.
+    """Batched encode()/convert() for many utterances: the same fragments the reference would send through the network one by
+    one (convert.py:151-165), as a few large batches on the GPU.
     specs: list of [T_i, 513] arrays.  decode_speakers: optional list of target speaker ids -> also returns the decoded
     spectrograms (enc_only path of convert()).  noise_fn(n_frag, T', E) -> Gumbel noise [n, T', E, 2] or None makes the
-    stochastic discretiser reproducible.  Returns (encodings list, decoded list or None); to_host=False leaves the decoded
-    spectrograms on the device (torch tensors [T_out, 513]) for spectrogram2wav_batch."""
+    stochastic discretiser reproducible (called once per batch; T' = encoded frames of the longest member).  Returns
+    (encodings list, decoded list or None); to_host=False leaves the decoded spectrograms on the device (torch tensors
+    [T_out, 513]) for spectrogram2wav_batch."""
     trainer.set_eval()
     enc, dec = trainer.Encoder, trainer.Decoder
     dev = trainer.device
@@ -282,18 +344,18 @@ def encode_batch(specs, trainer, seg_len, decode_speakers=None, noise_fn=None, m
     rest = sorted((it for it in items if it[3] - it[2] != seg_len), key=lambda it: it[2] - it[3])      # longest first
     chunks = [(full[lo:lo + max_batch], None) for lo in range(0, len(full), max_batch)]
     chunks += [(rest[lo:lo + max_batch], True) for lo in range(0, len(rest), max_batch)]
+    # every utterance goes to the device once, whole; the fragments are gathered there (row index tables, a few hundred KB)
+    rows, offs = _stage_rows(padded, dev)
+    zero_row = int(offs[-1])
     enc_out, dec_out = {}, {}
-    pending = []                                          # (chunk, lengths, device encodings, device spectrograms): one host sync at the end
+    pending = []                                          # (chunk, lengths, host encodings, spectrograms): one host sync at the end
     for chunk, ragged in chunks:
         lens = [b - a for (_, _, a, b, _) in chunk]
         Tm = max(lens)
-        if ragged:
-            xh = np.zeros((len(chunk), Tm, padded[0].shape[1]), dtype=np.float32)
-            for i, (u, _, a, b, _) in enumerate(chunk):
-                xh[i, :b - a] = padded[u][a:b]
-        else:
-            xh = np.stack([padded[u][a:b] for (u, _, a, b, _) in chunk])                               # [n, seg_len, 513]
-        x = torch.from_numpy(xh).to(dev, non_blocking=True)
+        idx = np.full((len(chunk), Tm), zero_row, dtype=np.int64)
+        for i, (u, _, a, b, _) in enumerate(chunk):
+            idx[i, :b - a] = np.arange(offs[u] + a, offs[u] + b)
+        x = rows[torch.from_numpy(idx).to(dev, non_blocking=True)]                                     # [n, Tm, 513]
         Tp = ((((Tm + 1) // 2 + 1) // 2) + 1) // 2
         G = noise_fn(len(chunk), Tp, enc.enc_size) if noise_fn is not None else None
         act, _ = enc(x.permute(0, 2, 1), G=G, lengths=(lens if ragged else None))
@@ -302,20 +364,27 @@ def encode_batch(specs, trainer, seg_len, decode_speakers=None, noise_fn=None, m
             ch = torch.tensor([decode_speakers[u] for (u, _, _, _, _) in chunk], dtype=torch.int64)
             lens_p = [((((n + 1) // 2 + 1) // 2) + 1) // 2 for n in lens]
             xd = dec(act, ch.to(dev, non_blocking=True), lengths=(lens_p if ragged else None)).permute(0, 2, 1)
-        pending.append((chunk, lens, act.permute(0, 2, 1), xd))
-    for chunk, lens, e_dev, xd_dev in pending:
-        e = e_dev.cpu().numpy()
-        xd = (xd_dev.cpu().numpy() if to_host else xd_dev) if xd_dev is not None else None
+            if to_host:
+                xd = _to_host(xd.contiguous())
+        pending.append((chunk, lens, _to_host(act.permute(0, 2, 1).contiguous()), xd))
+    torch.cuda.current_stream(dev).synchronize()
+    from . import layers
+    layers.check_status(dev)                                  # synchronised: a timed-out GRU pass raises here
+    for chunk, lens, e_host, xd in pending:
+        e = e_host.numpy()
+        if xd is not None and to_host:
+            xd = xd.numpy()
         for i, (u, k, _, _, trunc) in enumerate(chunk):
             tp = ((((lens[i] + 1) // 2 + 1) // 2) + 1) // 2
             enc_out[(u, k)] = e[i][:trunc] if trunc is not None else e[i][:tp]
             if xd is not None:
                 dec_out[(u, k)] = xd[i][:8 * tp]
-    from . import layers
-    layers.check_status(dev)                                  # the .cpu() copies synchronised: a timed-out GRU pass raises here
+    by_utt = {}
+    for (u, k) in enc_out:
+        by_utt.setdefault(u, []).append(k)
     encs, decs = [], ([] if decode_speakers is not None else None)
     for u in range(len(specs)):
-        ks = sorted(k for (uu, k) in enc_out if uu == u)
+        ks = sorted(by_utt[u])
         encs.append(np.concatenate([enc_out[(u, k)] for k in ks], axis=0))
         if decs is not None:
             parts = [dec_out[(u, k)] for k in ks]

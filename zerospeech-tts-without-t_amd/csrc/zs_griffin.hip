@@ -129,7 +129,8 @@ __global__ __launch_bounds__(256) void gl_iter_kernel(const ZsGlIter p, const fl
   extern __shared__ __align__(16) unsigned char gl_smem[];
   float2* W = reinterpret_cast<float2*>(gl_smem);
   float* win = reinterpret_cast<float*>(W + WTAB);
-  float2* wb = reinterpret_cast<float2*>(win + WLEN);
+  float* iwss = win + WLEN;                                                   // [HOP]: 1 / window-sum-square of interior samples
+  float2* wb = reinterpret_cast<float2*>(iwss + HOP);
   float* seg = reinterpret_cast<float*>(wb + NWAVE * WBUF);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int u = blockIdx.y;
@@ -145,6 +146,15 @@ __global__ __launch_bounds__(256) void gl_iter_kernel(const ZsGlIter p, const fl
   for (int j = tid; j < WLEN; j += 256) win[j] = g_gl_window[j];                                          // hann(800), periodic
   for (int j = tid; j < nseg; j += 256) seg[j] = 0.f;
   __syncthreads();
+  // A sample covered by four whole frames (everything but the first / last 400 samples of an utterance) sees the window-sum-square
+  // sum_m win^2(rho + 200 m), rho = (pos - WOFF) mod HOP, summed in the same order as the general loop below: 200 values per
+  // workgroup instead of a 4-term loop and a division per sample (read after the barriers of the overlap-add phases)
+  if (tid < HOP) {
+    float wss = 0.f;
+#pragma unroll
+    for (int m = 3; m >= 0; --m) { const float w = win[tid + HOP * m]; wss += w * w; }
+    iwss[tid] = 1.0f / wss;
+  }
 
   // ---- inverse transforms of frames i_lo..i_hi, overlap-added into seg (four phases: i mod 4) --------------------------
   const int i_lo = max(0, floordiv(n_lo - 400, HOP) + 1), i_hi = min(T - 1, (n_hi - 1 + 400) / HOP);
@@ -187,13 +197,27 @@ __global__ __launch_bounds__(256) void gl_iter_kernel(const ZsGlIter p, const fl
       }
       fft512<true>(v, mybuf, W, lane);
       const int nb = i * HOP - HALF;
+      constexpr float SC = 1.0f / 1024.0f;
+      if (nb + WOFF >= n_lo && nb + WOFF + WLEN <= n_hi) {                     // (wave-uniform) the whole windowed frame lies in the segment
+        float* sp = seg + (nb - n_lo);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int k = 2 * (lane + 64 * r);
-        const int n0 = nb + k;
-        if (k >= WOFF && k < WOFF + WLEN && n0 >= n_lo && n0 < n_hi) seg[n0 - n_lo] += v[r].x * (1.0f / 1024.0f) * win[k - WOFF];
-        if (k + 1 >= WOFF && k + 1 < WOFF + WLEN && n0 + 1 >= n_lo && n0 + 1 < n_hi)
-          seg[n0 + 1 - n_lo] += v[r].y * (1.0f / 1024.0f) * win[k + 1 - WOFF];
+        for (int r = 0; r < 8; ++r) {
+          const int k = 2 * (lane + 64 * r);
+          if ((r > 0 || k >= WOFF) && (r < 7 || k < WOFF + WLEN)) {          // WOFF and WLEN are even: k + 1 is inside with k
+            const float2 w2 = *reinterpret_cast<const float2*>(win + (k - WOFF));
+            sp[k] += v[r].x * SC * w2.x;
+            sp[k + 1] += v[r].y * SC * w2.y;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int k = 2 * (lane + 64 * r);
+          const int n0 = nb + k;
+          if (k >= WOFF && k < WOFF + WLEN && n0 >= n_lo && n0 < n_hi) seg[n0 - n_lo] += v[r].x * SC * win[k - WOFF];
+          if (k + 1 >= WOFF && k + 1 < WOFF + WLEN && n0 + 1 >= n_lo && n0 + 1 < n_hi)
+            seg[n0 + 1 - n_lo] += v[r].y * SC * win[k + 1 - WOFF];
+        }
       }
     }
     __syncthreads();
@@ -201,11 +225,17 @@ __global__ __launch_bounds__(256) void gl_iter_kernel(const ZsGlIter p, const fl
   // ---- window-sum-square normalisation (librosa.istft) --------------------------------------------------------------------
   for (int j = tid; j < nseg; j += 256) {
     const int pos = n_lo + j + HALF;
-    const int ia = max(0, (pos - (WOFF + WLEN - 1) + HOP - 1) / HOP), ib = min(T - 1, (pos - WOFF) / HOP);
-    float wss = 0.f;
-    for (int i = ia; i <= ib; ++i) { const float w = win[pos - i * HOP - WOFF]; wss += w * w; }
+    const int q = pos - WOFF;                                                  // >= 400
+    const int ib_raw = q / HOP, ia_raw = ib_raw - 3;                          // frames WOFF <= pos - i HOP < WOFF + WLEN
     float val = seg[j];
-    if (wss > 1.17549435e-38f) val /= wss;
+    if (ia_raw >= 0 && ib_raw <= T - 1) {
+      val *= iwss[q - ib_raw * HOP];
+    } else {
+      const int ia = max(0, ia_raw), ib = min(T - 1, ib_raw);
+      float wss = 0.f;
+      for (int i = ia; i <= ib; ++i) { const float w = win[pos - i * HOP - WOFF]; wss += w * w; }
+      if (wss > 1.17549435e-38f) val /= wss;
+    }
     seg[j] = val;
   }
   __syncthreads();
@@ -224,21 +254,34 @@ __global__ __launch_bounds__(256) void gl_iter_kernel(const ZsGlIter p, const fl
   for (int t = t0 + wave; t < t1; t += NWAVE) {
     float2 v[8];
     const int nb = t * HOP - HALF;
+    if (nb + WOFF >= n_lo && nb + WOFF + WLEN <= n_hi) {                       // (wave-uniform) no reflection at the utterance's ends:
+      const float* sp = seg + (nb - n_lo);                                    // every sample of the windowed frame is in the segment
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int k = 2 * (lane + 64 * r);
-      float x0 = 0.f, x1 = 0.f;
-      if (k >= WOFF && k < WOFF + WLEN) {                                     // k even, WOFF even: k + 1 is inside too
-        int a = nb + k, b = nb + k + 1;
-        if (a < 0) a = -a;
-        if (a >= L) a = 2 * (L - 1) - a;
-        if (b < 0) b = -b;
-        if (b >= L) b = 2 * (L - 1) - b;
-        a = min(max(a, n_lo), n_hi - 1); b = min(max(b, n_lo), n_hi - 1);     // (no-ops: the segment covers the reflections)
-        x0 = seg[a - n_lo] * win[k - WOFF];
-        x1 = seg[b - n_lo] * win[k + 1 - WOFF];
+      for (int r = 0; r < 8; ++r) {
+        const int k = 2 * (lane + 64 * r);
+        v[r] = make_float2(0.f, 0.f);
+        if ((r > 0 || k >= WOFF) && (r < 7 || k < WOFF + WLEN)) {
+          const float2 w2 = *reinterpret_cast<const float2*>(win + (k - WOFF));
+          v[r] = make_float2(sp[k] * w2.x, sp[k + 1] * w2.y);
+        }
       }
-      v[r] = make_float2(x0, x1);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int k = 2 * (lane + 64 * r);
+        float x0 = 0.f, x1 = 0.f;
+        if (k >= WOFF && k < WOFF + WLEN) {                                     // k even, WOFF even: k + 1 is inside too
+          int a = nb + k, b = nb + k + 1;
+          if (a < 0) a = -a;
+          if (a >= L) a = 2 * (L - 1) - a;
+          if (b < 0) b = -b;
+          if (b >= L) b = 2 * (L - 1) - b;
+          a = min(max(a, n_lo), n_hi - 1); b = min(max(b, n_lo), n_hi - 1);     // (no-ops: the segment covers the reflections)
+          x0 = seg[a - n_lo] * win[k - WOFF];
+          x1 = seg[b - n_lo] * win[k + 1 - WOFF];
+        }
+        v[r] = make_float2(x0, x1);
+      }
     }
     const float* M = Mu + (int64_t)t * NB;
     float mg[8];
@@ -259,8 +302,9 @@ __global__ __launch_bounds__(256) void gl_iter_kernel(const ZsGlIter p, const fl
       const float2 s = cadd(a, b), d = csub(a, b);
       const float2 tt = cmul(d, W[k]);
       const float2 e = make_float2(0.5f * (s.x + tt.y), 0.5f * (s.y - tt.x));   // E[k] = (a+b)/2 - (i/2) W^k (a-b)
-      const float mag = sqrtf(e.x * e.x + e.y * e.y);
-      const float sc = mg[r] / fmaxf(1e-8f, mag);                              // X = S * E / max(1e-8, |E|)   (convert.py:50)
+      // X = S * E / max(1e-8, |E|)   (convert.py:50) as S * E * rsqrt(max(1e-16, |E|^2)): one v_rsq_f32 (1 ulp) instead of a
+      // square root and a division (the projection was a fifth of the kernel's vector instructions)
+      const float sc = mg[r] * __builtin_amdgcn_rsqf(fmaxf(1e-16f, e.x * e.x + e.y * e.y));
       So[k] = make_float2(e.x * sc, e.y * sc);
     }
     if (lane == 0) {                                                          // Nyquist bin: E[512] = Re Z0 - Im Z0
@@ -306,9 +350,34 @@ __global__ __launch_bounds__(256) void gl_deemph_scan_kernel(float* wav, int64_t
   for (int i = lo; i < hi; ++i) { acc = (double)w[i] + a * acc; w[i] = (float)acc; }
 }
 
+// mean square of the centred frames of librosa.effects.trim (zs_gl_frame_mse): one workgroup per (frame, utterance)
+__global__ __launch_bounds__(256) void gl_frame_mse_kernel(const float* wav, int64_t wav_ld, const int32_t* lengths, int frame_length, int hop,
+                                                          double* mse, int64_t mse_ld) {
+  __shared__ double red[256];
+  const int u = blockIdx.y, f = blockIdx.x, tid = threadIdx.x;
+  const int L = HOP * (lengths[u] - 1);
+  if (L <= frame_length / 2 || f > L / hop) return;
+  const float* w = wav + (int64_t)u * wav_ld;
+  double acc = 0.0;
+  for (int i = tid; i < frame_length; i += 256) {
+    int j = f * hop + i - frame_length / 2;
+    if (j < 0) j = -j;
+    if (j >= L) j = 2 * (L - 1) - j;
+    const double v = (double)w[j];
+    acc += v * v;
+  }
+  red[tid] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0) mse[(int64_t)u * mse_ld + f] = red[0] / (double)frame_length;
+}
+
 std::atomic<int> g_gl_prefetch{0};
 
-size_t gl_lds_bytes(int F) { return (size_t)WTAB * 8 + WLEN * 4 + (size_t)NWAVE * WBUF * 8 + ((size_t)(F - 1) * HOP + 800) * 4; }
+size_t gl_lds_bytes(int F) { return (size_t)WTAB * 8 + WLEN * 4 + HOP * 4 + (size_t)NWAVE * WBUF * 8 + ((size_t)(F - 1) * HOP + 800) * 4; }
 
 int gl_launch(const ZsGlIter* p, const float* in, float* out, hipStream_t s) {
   const int F = p->tile_frames > 0 ? p->tile_frames : GL_TILE_DEFAULT;
@@ -352,6 +421,16 @@ extern "C" int zs_griffin_lim(const ZsGlIter* p, float* spec_a, float* spec_b, i
     float* t = cur; cur = nxt; nxt = t;
   }
   return gl_launch(p, cur, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int zs_gl_frame_mse(const float* wav, int64_t wav_ld, const int32_t* lengths, int32_t n_utt, int32_t frame_length, int32_t hop,
+                               double* mse, int64_t mse_ld, void* stream) {
+  ZS_REQUIRE(wav && lengths && mse && n_utt > 0 && frame_length > 0 && hop > 0 && mse_ld > 0, "zs_gl_frame_mse: bad args");
+  const int64_t n_frames = 1 + wav_ld / hop;                                  // upper bound over the utterances (rows hold <= wav_ld samples)
+  ZS_REQUIRE(mse_ld >= n_frames, "zs_gl_frame_mse: mse_ld %lld < %lld frames", (long long)mse_ld, (long long)n_frames);
+  hipLaunchKernelGGL(gl_frame_mse_kernel, dim3((unsigned)n_frames, (unsigned)n_utt), dim3(256), 0, (hipStream_t)stream, wav, wav_ld, lengths,
+                     frame_length, hop, mse, mse_ld);
+  return zs_check_launch("zs_gl_frame_mse");
 }
 
 extern "C" int zs_gl_deemphasis(float* wav, int64_t wav_ld, const int32_t* lengths, int32_t n_utt, float coef, void* stream) {
