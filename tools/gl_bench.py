@@ -30,7 +30,7 @@ def run(**kw):
 
 tiles = [int(t) for t in os.environ.get('GL_TILES', '6,8,10,12,14,18,26').split(',')]
 from zs_amd import _lib as L  # noqa: E402
-L.set_option('gl_prefetch', int(os.environ.get('GL_PREFETCH', '0')))
+L.set_option('gl_prefetch', int(os.environ.get('GL_PREFETCH', '1')))
 for kw in [dict(impl='split')] + [dict(impl='fused', tile_frames=t) for t in tiles]:
     dt = min(run(**kw) for _ in range(3))
     # 2 real 1024-point transforms per frame and iteration, 5 N log2 N / 2 flops each (N = 1024, real input)

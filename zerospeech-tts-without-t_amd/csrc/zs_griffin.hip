@@ -15,14 +15,16 @@
 //    two wave-private LDS exchanges between them (skewed by i + i/8 -> every ds access pattern of the three passes is
 //    bank-conflict free for a half-wave), no workgroup barrier inside the transform.  Twiddles: one LDS table of the
 //    1024th roots of unity per workgroup (the 512th and 64th roots are strided views), powers w^2..w^7 by multiplication.
-//  * Twiddle table, window, exchange buffers and segment take 36 KB of LDS at the default F = 10 -> four workgroups (16 waves)
-//    per CU.  Small tiles win although they transform 60 % more inverse frames (F = 10: 43 ms for 300 iterations of 64 utterances
-//    of 200..700 frames, F = 26: 51 ms, F = 42: 67 ms): the kernel is bound by the latency of its spectrum loads and of the four
-//    overlap-add phases, which more workgroups in flight hide; the spectrum of a wave's next frame is prefetched under the
-//    current transform.
+//  * Twiddle table, window, exchange buffers and segment take 37 KB of LDS at F = 10 with 4 waves -> four workgroups (16 waves)
+//    per CU; F = 26 with 8 waves: 68 KB -> two workgroups, the same 16 waves, 1.23 instead of 1.6 inverse transforms per frame.
+//    By the counters (profiles/r03_gl_counters.txt) the round-2 kernel spent 67 % of the vector-issue slots (it is NOT bound by
+//    the memory system: 2.7 TB/s): round 3 removed 26 % of its vector instructions (interior 1/window-sum-square table, wave-
+//    uniform fast paths without per-sample bounds checks, rsqrt projection) and requests a wave's next spectrum right behind
+//    the current transform: 36.9 -> 29.2 ms for 300 iterations of 64 utterances of 200..700 frames.
 // zs_griffin_lim runs the whole loop (n_iter launches ping-ponging two spectrogram buffers + the final inverse pass) from
 // one C call.  The older one-transform-per-workgroup kernels (zs_vocoder.hip) remain as the variant the tests compare with.
 #include <atomic>
+#include <mutex>
 
 #include "zs_common.h"
 
@@ -30,8 +32,8 @@ namespace {
 
 constexpr int NB = 513, HOP = 200, WLEN = 800, WOFF = 112, HALF = 512;
 constexpr int WBUF = 576;      // complex slots of a wave's exchange buffer: 512 + 512/8 skew
-constexpr int NWAVE = 4;
 constexpr int WTAB = 520;      // 513 roots, padded
+constexpr int GL_TILE_LARGE = 26;
 constexpr int GL_TILE_DEFAULT = 10;   // measured on 64 utterances of 200..700 frames: 10 -> 43 ms, 26 -> 51 ms, 42 -> 67 ms per 300 iterations
 
 __device__ __forceinline__ int padi(int i) { return i + (i >> 3); }
@@ -124,8 +126,12 @@ __global__ void gl_tables_kernel() {
 
 __device__ __forceinline__ int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
-template <bool PF>   // PF: prefetch the spectrum of a wave's next inverse frame under the current transform (+32 VGPRs)
-__global__ __launch_bounds__(256) void gl_iter_kernel(const ZsGlIter p, const float* spec_in, float* spec_out, int F) {
+// PF: request the spectrum of a wave's next inverse frame right behind the current transform (see below).  NWAVE: waves per
+// workgroup (4 or 8): a tile of F frames inverse-transforms F + 6 frames in four phases, so the phases are balanced over the waves
+// when F + 6 is a multiple of 4 NWAVE -- F = 10 with 4 waves (1.6 inverse transforms per frame), F = 26 with 8 waves (1.23).
+template <bool PF, int NWAVE>
+__global__ __launch_bounds__(64 * NWAVE) void gl_iter_kernel(const ZsGlIter p, const float* spec_in, float* spec_out, int F) {
+  constexpr int NT_ = 64 * NWAVE;
   extern __shared__ __align__(16) unsigned char gl_smem[];
   float2* W = reinterpret_cast<float2*>(gl_smem);
   float* win = reinterpret_cast<float*>(W + WTAB);
@@ -142,43 +148,46 @@ __global__ __launch_bounds__(256) void gl_iter_kernel(const ZsGlIter p, const fl
   const int L = HOP * (T - 1);
   const int n_lo = max(0, t0 * HOP - 400), n_hi = min(L, (t1 - 1) * HOP + 400);
   const int nseg = n_hi - n_lo;
-  for (int j = tid; j <= HALF; j += 256) W[j] = g_gl_roots[j];
-  for (int j = tid; j < WLEN; j += 256) win[j] = g_gl_window[j];                                          // hann(800), periodic
-  for (int j = tid; j < nseg; j += 256) seg[j] = 0.f;
+  for (int j = tid; j <= HALF; j += NT_) W[j] = g_gl_roots[j];
+  for (int j = tid; j < WLEN; j += NT_) win[j] = g_gl_window[j];                                          // hann(800), periodic
+  for (int j = tid; j < nseg; j += NT_) seg[j] = 0.f;
   __syncthreads();
   // A sample covered by four whole frames (everything but the first / last 400 samples of an utterance) sees the window-sum-square
   // sum_m win^2(rho + 200 m), rho = (pos - WOFF) mod HOP, summed in the same order as the general loop below: 200 values per
   // workgroup instead of a 4-term loop and a division per sample (read after the barriers of the overlap-add phases)
-  if (tid < HOP) {
+  for (int j = tid; j < HOP; j += NT_) {
+    const int tid_ = j;
     float wss = 0.f;
 #pragma unroll
-    for (int m = 3; m >= 0; --m) { const float w = win[tid + HOP * m]; wss += w * w; }
-    iwss[tid] = 1.0f / wss;
+    for (int m = 3; m >= 0; --m) { const float w = win[tid_ + HOP * m]; wss += w * w; }
+    iwss[tid_] = 1.0f / wss;
   }
 
   // ---- inverse transforms of frames i_lo..i_hi, overlap-added into seg (four phases: i mod 4) --------------------------
   const int i_lo = max(0, floordiv(n_lo - 400, HOP) + 1), i_hi = min(T - 1, (n_hi - 1 + 400) / HOP);
   float2* mybuf = wb + wave * WBUF;
   const float2* Sin = reinterpret_cast<const float2*>(spec_in) + (int64_t)u * p.T_max * NB;
+  // Frames of this wave: phase ph takes the frames i = i_lo + ((ph - i_lo) & 3) + 4 wave + 16 j.  PF: the spectrum of the wave's
+  // NEXT frame (in this or a later phase) is requested right after the current transform, so its latency runs under the
+  // overlap-add, the phase barrier and the other waves' work -- and not during the transform, where the registers are needed.
+  float2 xa[8], xb[8];
+  auto fetch = [&](int fi) {
+    const float2* X = Sin + (int64_t)fi * NB;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { xa[r] = X[lane + 64 * r]; xb[r] = X[HALF - lane - 64 * r]; }
+  };
+  auto first_of = [&](int ph) { return i_lo + ((ph - i_lo) & 3) + 4 * wave; };
+  if (PF) {
+    int ph0 = 0;
+    while (ph0 < 4 && first_of(ph0) > i_hi) ++ph0;
+    if (ph0 < 4) fetch(first_of(ph0));
+  }
 #pragma unroll 1
   for (int ph = 0; ph < 4; ++ph) {
-    const int first = i_lo + ((ph - i_lo) & 3);
-    // software pipeline: the spectrum of this wave's next frame is fetched while the current one is transformed
-    float2 xa[8], xb[8];
-    int i = first + 4 * wave;
-    if (PF && i <= i_hi) {
-      const float2* X = Sin + (int64_t)i * NB;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) { xa[r] = X[lane + 64 * r]; xb[r] = X[HALF - lane - 64 * r]; }
-    }
 #pragma unroll 1
-    for (; i <= i_hi; i += 4 * NWAVE) {
+    for (int i = first_of(ph); i <= i_hi; i += 4 * NWAVE) {
       float2 v[8];
-      if (!PF) {
-        const float2* X = Sin + (int64_t)i * NB;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { xa[r] = X[lane + 64 * r]; xb[r] = X[HALF - lane - 64 * r]; }
-      }
+      if (!PF) fetch(i);
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int k = lane + 64 * r;
@@ -190,12 +199,12 @@ __global__ __launch_bounds__(256) void gl_iter_kernel(const ZsGlIter p, const fl
         const float2 t = cmul(d, make_float2(w.x, -w.y));                    // d * exp(+2 pi i k / 1024)
         v[r] = make_float2(s.x - t.y, s.y + t.x);                            // Z = s + i t
       }
-      if (PF && i + 4 * NWAVE <= i_hi) {
-        const float2* X = Sin + (int64_t)(i + 4 * NWAVE) * NB;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { xa[r] = X[lane + 64 * r]; xb[r] = X[HALF - lane - 64 * r]; }
-      }
       fft512<true>(v, mybuf, W, lane);
+      if (PF) {                                                              // successor of (ph, i) in this wave's sequence
+        int nph = ph, ni = i + 4 * NWAVE;
+        while (ni > i_hi && ++nph < 4) ni = first_of(nph);
+        if (nph < 4) fetch(ni);
+      }
       const int nb = i * HOP - HALF;
       constexpr float SC = 1.0f / 1024.0f;
       if (nb + WOFF >= n_lo && nb + WOFF + WLEN <= n_hi) {                     // (wave-uniform) the whole windowed frame lies in the segment
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(256) void gl_iter_kernel(const ZsGlIter p, const fl
     __syncthreads();
   }
   // ---- window-sum-square normalisation (librosa.istft) --------------------------------------------------------------------
-  for (int j = tid; j < nseg; j += 256) {
+  for (int j = tid; j < nseg; j += NT_) {
     const int pos = n_lo + j + HALF;
     const int q = pos - WOFF;                                                  // >= 400
     const int ib_raw = q / HOP, ia_raw = ib_raw - 3;                          // frames WOFF <= pos - i HOP < WOFF + WLEN
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(256) void gl_iter_kernel(const ZsGlIter p, const fl
   if (spec_out == nullptr) {                                                  // final pass: the waveform is the result
     const int own_lo = tile == 0 ? 0 : t0 * HOP - 100, own_hi = tile == nt - 1 ? L : t1 * HOP - 100;
     float* wav = p.wav + (int64_t)u * p.wav_ld;
-    for (int n = own_lo + tid; n < own_hi; n += 256) wav[n] = seg[n - n_lo];
+    for (int n = own_lo + tid; n < own_hi; n += NT_) wav[n] = seg[n - n_lo];
     return;
   }
 
@@ -375,16 +384,31 @@ __global__ __launch_bounds__(256) void gl_frame_mse_kernel(const float* wav, int
   if (tid == 0) mse[(int64_t)u * mse_ld + f] = red[0] / (double)frame_length;
 }
 
-std::atomic<int> g_gl_prefetch{0};
+std::atomic<int> g_gl_prefetch{1};
+std::once_flag g_gl_lds_once;
 
-size_t gl_lds_bytes(int F) { return (size_t)WTAB * 8 + WLEN * 4 + HOP * 4 + (size_t)NWAVE * WBUF * 8 + ((size_t)(F - 1) * HOP + 800) * 4; }
+size_t gl_lds_bytes(int F, int nwave) { return (size_t)WTAB * 8 + WLEN * 4 + HOP * 4 + (size_t)nwave * WBUF * 8 + ((size_t)(F - 1) * HOP + 800) * 4; }
+
+void gl_set_lds_attr();
 
 int gl_launch(const ZsGlIter* p, const float* in, float* out, hipStream_t s) {
-  const int F = p->tile_frames > 0 ? p->tile_frames : GL_TILE_DEFAULT;
+  // default tile: 26 frames on 8 waves once the batch fills the chip (>= 8192 frames: 1.23 instead of 1.6 inverse transforms per
+  // frame, 29.2 against 30.9 ms for 300 iterations of 64 utterances of 200..700 frames), else 10 frames on 4 waves (more workgroups)
+  const int F = p->tile_frames > 0 ? p->tile_frames : ((int64_t)p->n_utt * p->T_max >= 8192 ? GL_TILE_LARGE : GL_TILE_DEFAULT);
   dim3 grid((unsigned)((p->T_max + F - 1) / F), (unsigned)p->n_utt);
-  if (g_gl_prefetch.load(std::memory_order_relaxed)) hipLaunchKernelGGL(gl_iter_kernel<true>, grid, dim3(256), gl_lds_bytes(F), s, *p, in, out, F);
-  else hipLaunchKernelGGL(gl_iter_kernel<false>, grid, dim3(256), gl_lds_bytes(F), s, *p, in, out, F);
+  const bool pf = g_gl_prefetch.load(std::memory_order_relaxed) != 0;
+  if (F > 16) {                                                               // large tiles: 8 waves share the segment
+    std::call_once(g_gl_lds_once, gl_set_lds_attr);
+    if (pf) hipLaunchKernelGGL((gl_iter_kernel<true, 8>), grid, dim3(512), gl_lds_bytes(F, 8), s, *p, in, out, F);
+    else hipLaunchKernelGGL((gl_iter_kernel<false, 8>), grid, dim3(512), gl_lds_bytes(F, 8), s, *p, in, out, F);
+  } else if (pf) hipLaunchKernelGGL((gl_iter_kernel<true, 4>), grid, dim3(256), gl_lds_bytes(F, 4), s, *p, in, out, F);
+  else hipLaunchKernelGGL((gl_iter_kernel<false, 4>), grid, dim3(256), gl_lds_bytes(F, 4), s, *p, in, out, F);
   return zs_check_launch("zs_gl_iter");
+}
+
+void gl_set_lds_attr() {                                                      // 8-wave tiles of F = 42 frames need 79 KB of LDS
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gl_iter_kernel<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gl_iter_kernel<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
 }
 
 int gl_check(const ZsGlIter* p, const char* what) {
