@@ -7,7 +7,7 @@ config 2  train_ae, english hps with enc_size = emb_size = 1024, **B = 256, bf16
 config 1  16 synthetic segments, 2 speakers, 10 iterations through Trainer.train(mode='pretrain_AE') (the reference's own loop,
           trainer.py:320-347) with the host DataLoader -> DevicePrefetcher in front, log / checkpoint cadence, and
           main.main(['--train_ae', '--synthetic', ...]).
-config 3  (DDP) rehearsed on ONE GPU: two rank processes on cuda:0 over gloo drive the product AEStep -- four-graph step ==
+config 3  (DDP) rehearsed on ONE GPU: two rank processes on cuda:0 over gloo drive the product AEStep -- multi-graph step ==
           eager step bit for bit, replicas stay bit-identical, and the 1/world-folded update equals a single-rank step on
           the global batch.
 
@@ -478,7 +478,7 @@ if rank == 0:
     out['norm_rel_err'] = [abs((s.item() ** 0.5) * 0.5 - s1.item() ** 0.5) / (s1.item() ** 0.5) for s, s1 in zip(sq, sq1)]
     out['param_err_over_lr'] = [((a - b).abs().max() / 1e-3).item() for a, b in zip(p_multi, [enc1.flat_params()[0], dec1.flat_params()[0]])]
 
-# (c) four-graph multi-rank step == eager multi-rank step, bit for bit; replicas stay identical
+# (c) multi-graph (bucketed) multi-rank step == eager multi-rank step, bit for bit; replicas stay identical
 res = []
 for mode in ('graph', 'eager'):
     enc, dec = build(5)
@@ -496,7 +496,7 @@ for mode in ('graph', 'eager'):
     layers.check_status(dev)
     res.append((losses, enc.flat_params()[0].clone(), dec.flat_params()[0].clone(), sum(len(v['graphs']) for v in ae._graphs.values())))
 (la, ea, da, na), (lb, eb, db, nb) = res
-assert na == 4 and nb == 0, (na, nb)
+assert na == 6 and nb == 0, (na, nb)         # fwd + dec head | dec convs | enc main | enc bank | dec update | enc update
 assert la == lb, (la, lb)
 assert torch.equal(ea, eb) and torch.equal(da, db), 'graph and eager multi-rank steps differ'
 for t in (ea, da):
@@ -544,7 +544,7 @@ def test_config3_two_ranks_on_one_gpu_gloo(dev, tmp_path):
     assert len(set(res['losses'])) == len(res['losses'])
 
 
-# ---- config 3 over RCCL: the multi-rank step (four hipGraphs, all-reduces between them) on ONE rank ------------------------
+# ---- config 3 over RCCL: the multi-rank step (six hipGraphs, five bucketed all-reduces between them) on ONE rank ------------------------
 
 _RCCL_SCRIPT = r'''
 import os, sys, json
@@ -581,9 +581,9 @@ for mode in ('rccl4', 'single'):
     layers.check_status(dev)
     res.append((losses, enc.flat_params()[0].clone(), dec.flat_params()[0].clone(), sum(len(v['graphs']) for v in ae._graphs.values())))
 (la, ea, da, na), (lb, eb, db, nb) = res
-assert na == 4 and nb == 1, (na, nb)
+assert na == 6 and nb == 1, (na, nb)
 assert la == lb, (la, lb)
-assert torch.equal(ea, eb) and torch.equal(da, db), 'the four-graph step over RCCL differs from the single-rank graph step'
+assert torch.equal(ea, eb) and torch.equal(da, db), 'the multi-graph step over RCCL differs from the single-rank graph step'
 print('RESULT ' + json.dumps({'losses': la, 'graphs': [na, nb]}), flush=True)
 dist.barrier()
 dist.destroy_process_group()
@@ -599,7 +599,7 @@ def _free_port():
 
 def test_config3_four_graph_step_over_rccl_one_rank(dev, tmp_path):
     """The multi-rank product path on the real communication backend: ONE child process (fresh: RCCL is initialised before any
-    other GPU work there), WORLD_SIZE=1 + ZS_FORCE_MULTI=1, backend 'nccl' (= RCCL).  The four-graph step with the two
+    other GPU work there), WORLD_SIZE=1 + ZS_FORCE_MULTI=1, backend 'nccl' (= RCCL).  The six-graph step with the five bucketed
     all-reduces issued between the graphs equals the single-rank one-graph step bit for bit over 6 replayed steps (a one-rank
     all-reduce is the identity and 1/world = 1), dropout and Gumbel noise on."""
     import subprocess
@@ -613,7 +613,7 @@ def test_config3_four_graph_step_over_rccl_one_rank(dev, tmp_path):
     line = [l for l in pr.stdout.splitlines() if l.startswith('RESULT ')]
     assert line, pr.stdout[-2000:]
     res = json.loads(line[0][7:])
-    assert res['graphs'] == [4, 1] and len(set(res['losses'])) == len(res['losses'])
+    assert res['graphs'] == [6, 1] and len(set(res['losses'])) == len(res['losses'])
 
 
 def test_bench_json_line_is_clean_over_rccl(dev):
@@ -629,7 +629,7 @@ def test_bench_json_line_is_clean_over_rccl(dev):
     lines = [l for l in pr.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, pr.stdout[-2000:]
     rec = json.loads(lines[0])
-    assert rec['n_gpus'] == 1 and rec['graph_segments'] == 4 and rec['hipgraph'] is True and rec['value'] > 0
+    assert rec['n_gpus'] == 1 and rec['graph_segments'] == 6 and rec['hipgraph'] is True and rec['value'] > 0
 
 
 def test_host_fed_step_equals_resident_step(dev):

@@ -177,8 +177,17 @@ def _dp_worker(rank, world, port, q):
     _, (ge, gd), _, _ = O.train_ae_grads(sub_sd(d, 'enc0.'), sub_sd(d, 'dec0.'), x[lo:hi], c[lo:hi], hp, G=G[lo:hi])
     flat = torch.cat([v.reshape(-1) for v in list(ge.values()) + list(gd.values())])
     red = parallel.GradReducer(bucket_bytes=64 << 10)          # several buckets
-    red.start(flat)
-    red.finish()
+    # tagged ranges in backward order (trainer.AEStep._multi_actions): the decoder's ranges first, the encoder's last; a wait
+    # for one tag leaves the other tag's collectives pending
+    ne = sum(v.numel() for v in ge.values())
+    cut = ne + (flat.numel() - ne) // 3
+    red.start(flat[cut:], tag='dec')
+    red.start(flat[ne:cut], tag='dec')
+    red.start(flat[:ne], tag='enc')
+    red.finish('dec')
+    assert red.pending and all(t == 'enc' for t, _, _, _ in red.pending)
+    red.finish('enc')
+    assert not red.pending
     assert red.scale == 0.5
     flat = flat * red.scale            # the buffers hold the SUM over ranks; the consumer (zs_adam_clip) folds 1/world in
     if rank == 0:
@@ -204,6 +213,26 @@ def test_data_parallel_gradient_average_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert world == 2 and err <= 2e-5 * scale, (err, scale)
+
+
+def test_gradient_buckets_partition_the_flat_buffers_in_backward_order():
+    """The bucket ranges of the data-parallel step (trainer.AEStep._multi_actions) tile each net's flat gradient buffer exactly,
+    and every bucket is a contiguous range whose parameters' gradients are final when its all-reduce starts."""
+    from zs_amd.model import Decoder, Encoder
+    enc = Encoder(c_in=80, c_h1=16, c_h2=32, c_h3=16, ns=0.01, dp=0.5, enc_size=8, seg_len=128, enc_mode='multilabel_binary')
+    dec = Decoder(c_in=8, c_out=80, c_h=32, c_a=4, ns=0.01, seg_len=128)
+    nd, ne = dec.flat_params()[1].numel(), enc.flat_params()[1].numel()
+    d_tail, d_conv, d_emb = dec.flat_range('dense1.weight', 'linear.bias'), dec.flat_range('conv1.weight', 'conv6.bias'), \
+        dec.flat_range('input_emb.weight', 'emb5.weight')
+    assert d_conv[0] == 0 and d_conv[1] == d_tail[0] and d_tail[1] == d_emb[0] and d_emb[1] == nd
+    e_bank, e_rest = enc.flat_range('conv1s.0.weight', 'conv1s.6.bias'), enc.flat_range('conv2.weight', 'linear.bias')
+    assert e_bank[0] == 0 and e_bank[1] == e_rest[0] and e_rest[1] == ne
+    names = [n for n, _ in dec.named_parameters()]
+    lo = names.index('dense1.weight')
+    assert names[lo:names.index('input_emb.weight')] == [n for n in names if n.split('.')[0] in
+                                                         ('dense1', 'dense2', 'dense3', 'dense4', 'RNN', 'dense5', 'linear')]
+    with pytest.raises(ValueError):
+        dec.flat_range('linear.bias', 'conv1.weight')
 
 
 def test_data_parallel_loader_shards_are_disjoint():

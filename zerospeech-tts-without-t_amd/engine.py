@@ -167,6 +167,12 @@ class EncoderEngine(object):
     def backward(self, dbits, dlogits_extra=None):
         """dbits: Act [B,T',E] gradient w.r.t. enc_act (may be None); dlogits_extra: Act [B,T',2E] gradient w.r.t. the
         pre-activation `enc` (speaker-classifier term of trainer.py:444).  Fills every encoder parameter gradient."""
+        self.backward_main(dbits, dlogits_extra)
+        self.backward_bank()
+
+    def backward_main(self, dbits, dlogits_extra=None):
+        """Everything but the conv bank's seven weight gradients (the last gradients of the step: data parallel training starts
+        the all-reduce of the rest of the encoder before them, trainer.AEStep)."""
         c, ns, tp = self.ctx, self.ns, self.tape
         assert tp is not None and tp['training']
         B, T, Ts, T4 = tp['B'], tp['T'], tp['Ts'], tp['T4']
@@ -225,8 +231,12 @@ class EncoderEngine(object):
         # only the conv bank's 7*c_h1 columns are consumed: the pass-through columns of the concatenation are the gradient w.r.t.
         # the input spectrogram, which the reference computes and drops (utils.py:43-45) -- a third of this GEMM
         self.conv2.dgrad(dz, T, dcat, dact_src=cat, slope=ns, n_cols=7 * c1)
+        self._bank = (dcat, xin)
+
+    def backward_bank(self):
+        dcat, xin = self._bank
         for i, l in enumerate(self.conv1s):
-            l.wgrad(dcat.sub(i * c1, c1), xin)
+            l.wgrad(dcat.sub(i * self.c1, self.c1), xin)
 
     def _combine(self, gp, T, pl, pr, out, res_mode=L.ZS_RES_NONE, res=None, dact=None):
         c = self.ctx
@@ -363,6 +373,13 @@ class DecoderEngine(object):
     def backward(self, dlogit, need_dbits=True):
         """dlogit: Act [B,T,F] gradient w.r.t. the pre-sigmoid output.  Fills (overwrites) every decoder parameter
         gradient.  Returns dbits Act [B,T',E]."""
+        self.backward_head(dlogit)
+        return self.backward_convs(need_dbits)
+
+    def backward_head(self, dlogit):
+        """linear, dense5, the GRU and the two dense blocks: the gradients of dense1 .. linear (a contiguous range of the flat
+        gradient buffer) are final when this returns and the side streams have been joined -- data parallel training starts their
+        all-reduce here, under the conv blocks' backward (trainer.AEStep)."""
         c, ns, ch, tp = self.ctx, self.ns, self.ch, self.tape
         assert tp is not None and tp['training']
         B, T0, T = tp['B'], tp['T0'], tp['T']
@@ -427,6 +444,13 @@ class DecoderEngine(object):
                 la.dgrad(dz1, T, gpv)
                 self._combine(gpv, T, 0, 0, dn, emb_i=3, res_mode=L.ZS_RES_IDENTITY, res=dx)
             dx = dn
+        self._bw = (dx, gp, tag)
+
+    def backward_convs(self, need_dbits=True):
+        """The three conv blocks, the embeddings and input_emb.  Returns dbits."""
+        c, ns, ch, tp = self.ctx, self.ns, self.ch, self.tape
+        dx, gp, tag = self._bw
+        B, T0 = tp['B'], tp['T0']
         for i in (2, 1, 0):
             la, lb = self.convs[i]
             xin, xe, ya, s, yb, stt, Ti = tp['blocks'][i]

@@ -63,6 +63,18 @@ class ZsModule(nn.Module):
         p = dict(self.named_parameters())[name]
         return self._zs['gflat'][o:o + p.numel()].view(p.shape)
 
+    def flat_range(self, first, last):
+        """(lo, hi) element range of the flat parameter / gradient buffers that holds the parameters `first` .. `last`
+        (registration order), e.g. a gradient bucket of the data-parallel all-reduce."""
+        if self._zs['flat'] is None:
+            self._flatten()
+        offs = self._zs['offsets']
+        p = dict(self.named_parameters())[last]
+        lo, hi = offs[first], offs[last] + rup(p.numel(), 4)
+        if lo >= hi:
+            raise ValueError('flat_range: %s does not precede %s' % (first, last))
+        return lo, hi
+
     def mark_dirty(self):
         self._zs['version'] = None
 

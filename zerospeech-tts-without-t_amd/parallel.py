@@ -34,7 +34,7 @@ def world_size():
 
 def multi_rank():
     """True when the data-parallel code path is to be taken: more than one rank, or ZS_FORCE_MULTI=1 (a one-rank rehearsal of the
-    multi-rank step -- four hipGraphs with RCCL all-reduces between them -- on a single GPU)."""
+    multi-rank step -- one hipGraph per segment with the bucketed RCCL all-reduces between them -- on a single GPU)."""
     return world_size() > 1 or (os.environ.get('ZS_FORCE_MULTI') == '1' and dist.is_available() and dist.is_initialized())
 
 
@@ -66,7 +66,8 @@ class GradReducer(object):
     def scale(self):
         return 1.0 / world_size()
 
-    def start(self, flat):
+    def start(self, flat, tag=None):
+        """tag: any label (e.g. the net's name); finish(tag) waits for the collectives started under it."""
         if not multi_rank():
             return
         n = flat.numel()
@@ -75,24 +76,24 @@ class GradReducer(object):
             if h is None or h.numel() != n:
                 h = self._half[flat.data_ptr()] = torch.empty(n, dtype=torch.bfloat16, device=flat.device)
             h.copy_(flat)
-            self.pending.append((flat, h, dist.all_reduce(h, op=dist.ReduceOp.SUM, async_op=True)))
+            self.pending.append((tag, flat, h, dist.all_reduce(h, op=dist.ReduceOp.SUM, async_op=True)))
             return
         for lo in range(0, n, self.bucket_elems):
             chunk = flat[lo:min(n, lo + self.bucket_elems)]
-            self.pending.append((chunk, None, dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True)))
+            self.pending.append((tag, chunk, None, dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True)))
 
-    def mark(self):
-        """Number of collectives started so far (argument of finish(upto=...))."""
-        return len(self.pending)
-
-    def finish(self, upto=None):
-        """Make the current stream wait for the first `upto` pending collectives (all of them by default)."""
-        n = len(self.pending) if upto is None else min(upto, len(self.pending))
-        for dst, half, work in self.pending[:n]:
+    def finish(self, tag=None):
+        """Make the current stream wait for the pending collectives started under `tag` (all of them when tag is None)."""
+        keep = []
+        for ent in self.pending:
+            t, dst, half, work = ent
+            if tag is not None and t != tag:
+                keep.append(ent)
+                continue
             work.wait()
             if half is not None:
                 dst.copy_(half)
-        self.pending = self.pending[n:]
+        self.pending = keep
 
 
 def broadcast_params(nets, src=0):

@@ -33,9 +33,9 @@ class AEStep(object):
     Graph mode (ZS_GRAPH=1, default): after two eager warm-up steps the ~600 kernel launches of a step are captured
     into hipGraphs and replayed, so the host cost per step is a handful of calls instead of ~15 ms of Python/ctypes
     launches.  Everything that changes from step to step lives in device memory (RNG seed, Adam step count:
-    zs_step_counters).  With more than one rank the step is four graphs (fwd + decoder bwd | encoder bwd | decoder optimizer |
-    encoder optimizer) with the RCCL all-reduces launched eagerly between them: the decoder's reduce overlaps the encoder bwd, the
-    encoder's the decoder's optimizer."""
+    zs_step_counters).  With more than one rank the step is one graph per segment of _multi_actions (forward + decoder tail
+    backward | decoder conv blocks | encoder backward | conv bank weight gradients | decoder optimizer | encoder optimizer) with
+    the RCCL all-reduces of the gradient buckets launched eagerly between them, each as soon as its bucket is final."""
 
     def __init__(self, encoder, decoder, lr=1e-4, betas=(0.5, 0.9), max_grad_norm=5.0, use_graph=None):
         self.Encoder, self.Decoder = encoder, decoder
@@ -60,13 +60,17 @@ class AEStep(object):
         self._dec_updated = False
         self.fetch_by_kernel = os.environ.get('ZS_FETCH_KERNEL', '1') == '1'     # in-graph H2D by zs_host_fetch instead of a memcpy node
         self.fetch_wgs = int(os.environ.get('ZS_FETCH_WGS', '32'))
+        # data parallel: gradient buckets in backward order (decoder tail layers first, the encoder's conv bank last), each
+        # all-reduce started as soon as its range of the flat gradient buffer is final (ZS_DP_BUCKETS=0: one per net)
+        self.buckets = os.environ.get('ZS_DP_BUCKETS', '1') == '1'
         self._graphs = {}            # (B, T, F) -> dict(graphs=[...], x=static x, c=static c)
         self._statics = {}           # (B, T, F) -> (x, c) handed out by static_inputs()
         self._eager_calls = 0
         self.graph_warmup = 2        # eager steps (same launches) before the capture
 
     # ---- the stream-ordered segments of a step --------------------------------------------------------------------
-    def _seg_forward_decbwd(self, x_btf, c, noise, noise_kind, drop_masks, seed, seed_ptr):
+    def _seg_forward(self, x_btf, c, noise, noise_kind, drop_masks, seed, seed_ptr):
+        """Encoder + Decoder forward and the L1 loss; returns dlogit (the gradient w.r.t. the pre-sigmoid output)."""
         enc, dec = self.Encoder, self.Decoder
         ee, de = enc._engine(), dec._engine()
         ctx = ee.ctx
@@ -77,8 +81,67 @@ class AEStep(object):
         L.call('zs_l1_loss', 'ZsL1Loss', ctx.stream, dtype=ctx.dt, x_dec=xdec.ptr(), ld_dec=xdec.ld, x=L.ptr(x_btf), ldx=F,
                rows=B * xdec.T, F=F, dlogits=dlogit.ptr(), ldg=dlogit.ld, fill_cols=dlogit.ld, partial=L.ptr(self._lpart),
                loss_out=L.ptr(self._loss), grad_scale=1.0)                                   # trainer.py:328
-        self._dbits = de.backward(dlogit)                                                    # loss.backward(), trainer.py:330
         self.xdec = xdec
+        return dlogit
+
+    def _seg_forward_decbwd(self, x_btf, c, noise, noise_kind, drop_masks, seed, seed_ptr):
+        dlogit = self._seg_forward(x_btf, c, noise, noise_kind, drop_masks, seed, seed_ptr)
+        self._dbits = self.Decoder._engine().backward(dlogit)                                # loss.backward(), trainer.py:330
+
+    def _multi_actions(self, x_btf, c, noise, noise_kind, drop_masks, seed, seed_ptr, counted):
+        """The data-parallel step as an ordered list of actions: ('run', fn) = launches on the current stream (one hipGraph each
+        in graph mode), ('reduce', net name, lo, hi) = start the all-reduce of that range of the net's flat gradient buffer (a
+        bucket), ('wait', net name) = the current stream waits for that net's all-reduces, ('update', net name) = the per-net clip +
+        Adam.  Buckets in backward order: decoder dense1 .. linear (50 MB) start under the decoder's conv blocks, the conv blocks +
+        embeddings (120 MB) under the encoder's backward, the encoder without its conv bank (47 MB) under the bank's seven weight
+        gradients, the bank (7 MB) last; every 'run' ends with the side streams joined, so its gradients are final."""
+        enc, dec = self.Encoder, self.Decoder
+        ee, de = enc._engine(), dec._engine()
+        st = {}
+
+        def fwd_and_dec_head():
+            if counted:
+                L.check(L.lib().zs_step_counters(L.ptr(self._seed_dev), L.ptr(self._step_dev), torch.cuda.current_stream(self.device).cuda_stream),
+                        'zs_step_counters')
+            st['dlogit'] = self._seg_forward(x_btf, c, noise, noise_kind, drop_masks, seed, seed_ptr)
+            if self.buckets:
+                de.backward_head(st['dlogit'])
+            else:
+                self._dbits = de.backward(st['dlogit'])
+            join_side(self.device)
+
+        def dec_convs():
+            self._dbits = de.backward_convs()
+            join_side(self.device)
+
+        def enc_main():
+            ee.backward_main(self._dbits)
+            join_side(self.device)
+
+        def enc_bank():
+            ee.backward_bank()
+            join_side(self.device)
+
+        acts = [('run', fwd_and_dec_head)]
+        if self.buckets:
+            acts += [('reduce', 'dec') + dec.flat_range('dense1.weight', 'linear.bias'), ('run', dec_convs),
+                     ('reduce', 'dec') + dec.flat_range('conv1.weight', 'conv6.bias'),
+                     ('reduce', 'dec') + dec.flat_range('input_emb.weight', 'emb5.weight'),
+                     ('run', enc_main), ('reduce', 'enc') + enc.flat_range('conv2.weight', 'linear.bias'),
+                     ('run', enc_bank), ('reduce', 'enc') + enc.flat_range('conv1s.0.weight', 'conv1s.6.bias')]
+        else:
+            acts += [('reduce', 'dec', 0, dec.flat_params()[1].numel()), ('run', self._seg_encbwd),
+                     ('reduce', 'enc', 0, enc.flat_params()[1].numel())]
+        # the decoder's clip + Adam + re-pack run while the encoder's all-reduces are still in flight
+        return acts + [('wait', 'dec'), ('update', 'dec'), ('wait', 'enc'), ('update', 'enc')]
+
+    def _do_action(self, a):
+        """Execute a 'reduce' / 'wait' action (the 'run' / 'update' actions are launches: eager or captured)."""
+        net = self.Decoder if a[1] == 'dec' else self.Encoder
+        if a[0] == 'reduce':
+            self.reducer.start(net.flat_params()[1][a[2]:a[3]], tag=a[1])
+        elif a[0] == 'wait':
+            self.reducer.finish(a[1])
 
     def _seg_encbwd(self):
         self.Encoder._engine().backward(self._dbits)
@@ -96,14 +159,15 @@ class AEStep(object):
             return self._graph_step(x_btf, c, multi)
         if seed is None:
             seed = (self.adam_step + 1) * 0x9E3779B97F4A7C15 % (1 << 63) + parallel.rank()
-        self._seg_forward_decbwd(x_btf, c, noise, noise_kind, drop_masks, seed, None)
         if multi:
-            join_side(self.device)                 # decoder weight gradients (side stream) must be complete
-            self.reducer.start(dec.flat_params()[1])
-        self._seg_encbwd()
-        if multi:
-            self.reducer.start(enc.flat_params()[1])
-            self.reducer.finish()
+            for a in self._multi_actions(x_btf, c, noise, noise_kind, drop_masks, seed, None, counted=False):
+                if a[0] == 'run':
+                    a[1]()
+                elif a[0] != 'update':             # (the update below: host-side bias correction, optional)
+                    self._do_action(a)
+        else:
+            self._seg_forward_decbwd(x_btf, c, noise, noise_kind, drop_masks, seed, None)
+            self._seg_encbwd()
         if update:
             self.optimizer_step()
         return self._loss
@@ -111,26 +175,22 @@ class AEStep(object):
     # ---- graph mode ------------------------------------------------------------------------------------------------
     def _counted_step_eager(self, x_btf, c, multi):
         """Same launches as the captured step (device-side seed / step count), executed eagerly."""
-        st = torch.cuda.current_stream(self.device).cuda_stream
-        enc, dec = self.Encoder, self.Decoder
-        L.check(L.lib().zs_step_counters(L.ptr(self._seed_dev), L.ptr(self._step_dev), st), 'zs_step_counters')
-        self._seg_forward_decbwd(x_btf, c, None, 2, None, parallel.rank(), L.ptr(self._seed_dev))
         if multi:
-            join_side(self.device)
-            self.reducer.start(dec.flat_params()[1])
-        elif self.early_dec_update:
-            self._early_decoder_update()
-        n_dec = self.reducer.mark()
-        self._seg_encbwd()
-        if multi:
-            # the decoder's clip + Adam + re-pack run while the encoder's all-reduce is still in flight
-            self.reducer.start(enc.flat_params()[1])
-            self.reducer.finish(upto=n_dec)
-            self._net_device_update('dec', self.Decoder)
-            self.reducer.finish()
-            self._net_device_update('enc', self.Encoder)
+            for a in self._multi_actions(x_btf, c, None, 2, None, parallel.rank(), L.ptr(self._seed_dev), counted=True):
+                if a[0] == 'run':
+                    a[1]()
+                elif a[0] == 'update':
+                    self._net_device_update(a[1], self.Decoder if a[1] == 'dec' else self.Encoder)
+                else:
+                    self._do_action(a)
             self.adam_step += 1
             return
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(L.lib().zs_step_counters(L.ptr(self._seed_dev), L.ptr(self._step_dev), st), 'zs_step_counters')
+        self._seg_forward_decbwd(x_btf, c, None, 2, None, parallel.rank(), L.ptr(self._seed_dev))
+        if self.early_dec_update:
+            self._early_decoder_update()
+        self._seg_encbwd()
         self._optimizer_device_step()
 
     def _net_device_update(self, name, net):
@@ -219,9 +279,8 @@ class AEStep(object):
                 torch.cuda.current_stream(self.device).wait_event(state['ev'])
                 state['ev'] = None
 
-        def seg1():
+        def fork_prefetch():
             main = torch.cuda.current_stream(self.device)
-            st = main.cuda_stream
             if prefetch is not None:
                 # The fetch of the NEXT batch forks at the very start of the graph and joins at its very end: measured with kernel
                 # traces, wherever the branch forks the executor of this ROCm stack does not run it truly
@@ -240,50 +299,62 @@ class AEStep(object):
                         prefetch[2].copy_(prefetch[3], non_blocking=True)
                     state['ev'] = torch.cuda.Event()
                     state['ev'].record(cs_)
-            L.check(L.lib().zs_step_counters(L.ptr(self._seed_dev), L.ptr(self._step_dev), st), 'zs_step_counters')
-            self._seg_forward_decbwd(xs, cs, None, 2, None, parallel.rank(), st_ptr)
-            if multi:
-                join_side(self.device)
-                join_prefetch()                                    # several graphs: the branch must end inside the first
-            elif self.early_dec_update:
-                self._early_decoder_update()
 
-        def seg3():
+        def single():
+            fork_prefetch()
+            L.check(L.lib().zs_step_counters(L.ptr(self._seed_dev), L.ptr(self._step_dev), torch.cuda.current_stream(self.device).cuda_stream),
+                    'zs_step_counters')
+            self._seg_forward_decbwd(xs, cs, None, 2, None, parallel.rank(), st_ptr)
+            if self.early_dec_update:
+                self._early_decoder_update()
+            self._seg_encbwd()
             self._optimizer_device_step()
             self.adam_step = step0                             # capture does not execute: the caller counts the step
+            # the fetch branch joins at the very END of the graph (wherever the executor schedules it, it then runs beside the
+            # encoder's backward instead of holding it up)
+            join_prefetch()
 
-        def seg3_dec():                                        # multi-rank: the optimizer in two graphs, so that the decoder's
-            self._net_device_update('dec', self.Decoder)       # update runs under the encoder's all-reduce
+        pool = [None]
 
-        def seg3_enc():
-            self._net_device_update('enc', self.Encoder)
-
-        pool = None
-        # single rank: the fetch branch joins at the very END of the graph (wherever the executor schedules it, it then runs
-        # beside the encoder's backward instead of holding it up)
-        segs = [lambda: (seg1(), self._seg_encbwd(), seg3(), join_prefetch())] if not multi else [seg1, self._seg_encbwd, seg3_dec, seg3_enc]
-        for seg in segs:
+        def capture(fn):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):   # other threads (RCCL watchdog) may call HIP
-                seg()
-            pool = g.pool()
+            with torch.cuda.graph(g, pool=pool[0], capture_error_mode='thread_local'):   # other threads (RCCL watchdog) may call HIP
+                fn()
+            pool[0] = g.pool()
             graphs.append(g)
-        return {'graphs': graphs, 'x': xs, 'c': cs}
+            return g
+
+        if not multi:
+            capture(single)
+            return {'graphs': graphs, 'x': xs, 'c': cs, 'plan': None}
+        # data parallel: one graph per 'run' / 'update' action, the all-reduces are issued between the replays
+        plan = []
+        first = [True]
+        for a in self._multi_actions(xs, cs, None, 2, None, parallel.rank(), st_ptr, counted=True):
+            if a[0] == 'run':
+                def seg(fn=a[1], with_fetch=first[0]):
+                    if with_fetch:
+                        fork_prefetch()
+                    fn()
+                    if with_fetch:
+                        join_prefetch()                            # several graphs: the branch must end inside the first
+                first[0] = False
+                plan.append(('graph', capture(seg)))
+            elif a[0] == 'update':
+                plan.append(('graph', capture(lambda n=a[1]: self._net_device_update(n, self.Decoder if n == 'dec' else self.Encoder))))
+            else:
+                plan.append(a)
+        return {'graphs': graphs, 'x': xs, 'c': cs, 'plan': plan}
 
     def _replay(self, ent, multi):
         if not multi:
             ent['graphs'][0].replay()
         else:
-            g1, g2, g3d, g3e = ent['graphs']
-            g1.replay()
-            self.reducer.start(self.Decoder.flat_params()[1])
-            n_dec = self.reducer.mark()
-            g2.replay()
-            self.reducer.start(self.Encoder.flat_params()[1])
-            self.reducer.finish(upto=n_dec)
-            g3d.replay()                                       # decoder clip + Adam + re-pack under the encoder's all-reduce
-            self.reducer.finish()
-            g3e.replay()
+            for a in ent['plan']:
+                if a[0] == 'graph':
+                    a[1].replay()
+                else:
+                    self._do_action(a)
         self.adam_step += 1
 
     def host_feeder(self, loader):
