@@ -479,6 +479,11 @@ typedef struct {
   void* out; int64_t ldo;                         /* [B][H_out][Wd] rows of ldo >= k*C elements (T dtype; zeros past k*C) */
   int32_t B, H_in, H_out, Wd, C;
   int32_t k, stride, pad, pad_mode;
+  /* full != 0: im2col along BOTH axes (the first layer, C = 1: the H-only gather pads its 5 columns per tap to a whole 128-byte
+   * K chunk, 12.8 x the input; all 25 taps fit ONE chunk).  Output rows (b, ho, wo), wo < W_out = (Wd + 2 pad - k) / stride + 1,
+   * columns (kh*k + kw)*C + c = x[b, pad(stride*ho + kh - pad), pad(stride*wo + kw - pad), c]; the convolution is then a
+   * 1-tap zs_gemm_conv over these rows.  zs_conv2d_fold(full) is its transpose. */
+  int32_t full;
 } ZsConv2dGather;
 int zs_conv2d_gather(const ZsConv2dGather* p, void* stream);
 typedef struct {
@@ -489,6 +494,9 @@ typedef struct {
   const void* add; int64_t ldadd;                 /* optional rows added (T dtype, same shape as out) */
   int32_t B, H_in, H_out, Wd, C;
   int32_t k, stride, pad, pad_mode;
+  int32_t gp_rows;                                /* rows of gp per (b, h_out) block; 0 = Wd + 2*pad (a stride-2 data gradient is
+                                                     computed by output parity and keeps an even number of rows per block) */
+  int32_t full;                                   /* transpose of zs_conv2d_gather(full): gp rows (b, ho, wo), columns (kh*k + kw)*C + c */
 } ZsConv2dFold;
 int zs_conv2d_fold(const ZsConv2dFold* p, void* stream);
 

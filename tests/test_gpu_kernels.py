@@ -157,7 +157,7 @@ def test_conv_epilogue_split2_vec(zs, dtype, gemm_variant):
 
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('case', [(2, 16, 32, 48, 5, 1), (2, 16, 32, 48, 5, 2), (3, 12, 64, 32, 3, 1), (2, 10, 40, 24, 1, 1),
-                                  (2, 128, 96, 80, 5, 2), (4, 200, 300, 520, 3, 1), (3, 130, 136, 250, 1, 1)])
+                                  (2, 128, 96, 80, 5, 2), (3, 64, 64, 256, 5, 2), (4, 200, 300, 520, 3, 1), (3, 130, 136, 250, 1, 1)])
 def test_conv_backward(zs, dtype, case, gemm_variant):
     """dgrad (padded domain) + reflect fold + lrelu' ; wgrad ; bias grad -- against autograd."""
     L, layers = zs

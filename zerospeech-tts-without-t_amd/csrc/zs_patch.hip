@@ -73,6 +73,82 @@ __global__ __launch_bounds__(NTP) void conv2d_gather_kernel(const ZsConv2dGather
   }
 }
 
+// im2col along both axes (ZsConv2dGather.full): one thread per (output row (b, ho, wo), 8-column group)
+template <typename T>
+__global__ __launch_bounds__(NTP) void conv2d_im2col_kernel(const ZsConv2dGather p, int W_out) {
+  const int groups = (int)(p.ldo / 8);
+  const int64_t total = (int64_t)p.B * p.H_out * W_out * groups;
+  const int kkc = p.k * p.k * p.C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % groups);
+    const int64_t row = i / groups;
+    const int wo = (int)(row % W_out);
+    const int64_t bh = row / W_out;
+    const int ho = (int)(bh % p.H_out), b = (int)(bh / p.H_out);
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int col = g * 8 + e;
+      float v = 0.f;
+      if (col < kkc) {
+        const int tap = col / p.C, c = col - tap * p.C;
+        const int kh = tap / p.k, kw = tap - kh * p.k;
+        bool vh, vw;
+        const int hi = pad_index(p.stride * ho + kh - p.pad, p.H_in, p.pad_mode, vh);
+        const int wi = pad_index(p.stride * wo + kw - p.pad, p.Wd, p.pad_mode, vw);
+        if (vh && vw) {
+          const int64_t src = (((int64_t)b * p.H_in + hi) * p.Wd + wi) * p.ldx + c;
+          v = p.x_f32 ? ((const float*)p.x)[src] : Elem<T>::ld((const T*)p.x + src);
+        }
+      }
+      o[e] = v;
+    }
+    store8<T>((T*)p.out + row * p.ldo + g * 8, o);
+  }
+}
+
+// transpose of the above (ZsConv2dFold.full): dX[b, hi, w, c] = sum over (ph in {hi, reflection partners}, kh -> ho) x
+// (pw in {w, reflection partners}, kw -> wo) of gp[(b, ho, wo), (kh*k + kw)*C + c]; one thread per (b, hi, w, c), fixed order
+template <typename T>
+__global__ __launch_bounds__(NTP) void conv2d_col2im_kernel(const ZsConv2dFold p, int W_out) {
+  const int64_t total = (int64_t)p.B * p.H_in * p.Wd * p.C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % p.C);
+    const int64_t row = i / p.C;
+    const int w = (int)(row % p.Wd);
+    const int64_t bh = row / p.Wd;
+    const int hi = (int)(bh % p.H_in), b = (int)(bh / p.H_in);
+    int hs[3], ws[3], nh = 0, nw = 0;
+    hs[nh++] = hi;
+    ws[nw++] = w;
+    if (p.pad_mode == ZS_PAD_REFLECT) {
+      if (hi >= 1 && hi <= p.pad) hs[nh++] = -hi;
+      if (hi <= p.H_in - 2 && hi >= p.H_in - 1 - p.pad) hs[nh++] = 2 * (p.H_in - 1) - hi;
+      if (w >= 1 && w <= p.pad) ws[nw++] = -w;
+      if (w <= p.Wd - 2 && w >= p.Wd - 1 - p.pad) ws[nw++] = 2 * (p.Wd - 1) - w;
+    }
+    float acc = 0.f;
+    for (int a = 0; a < nh; ++a)
+      for (int kh = 0; kh < p.k; ++kh) {
+        const int nh_ = hs[a] + p.pad - kh;
+        if (nh_ < 0 || nh_ % p.stride != 0) continue;
+        const int ho = nh_ / p.stride;
+        if (ho >= p.H_out) continue;
+        for (int q = 0; q < nw; ++q)
+          for (int kw = 0; kw < p.k; ++kw) {
+            const int nw_ = ws[q] + p.pad - kw;
+            if (nw_ < 0 || nw_ % p.stride != 0) continue;
+            const int wo = nw_ / p.stride;
+            if (wo >= W_out) continue;
+            acc += Elem<T>::ld((const T*)p.gp + (((int64_t)b * p.H_out + ho) * W_out + wo) * p.ldg + (int64_t)(kh * p.k + kw) * p.C + c);
+          }
+      }
+    if (p.add) acc += Elem<T>::ld((const T*)p.add + row * p.ldadd + c);
+    if (p.out_f32) ((float*)p.out)[row * p.ldo + c] = acc;
+    else Elem<T>::st((T*)p.out + row * p.ldo + c, acc);
+  }
+}
+
 // ---- Conv2d data gradient: fold the W-padded / H-gathered gradient back -----------------------------------------------------
 // dX[b, hi, w, c] = sum over (ph in {hi and its reflection partners}, kh with (ph + pad - kh) % stride == 0 -> ho) and over
 //                   (wp in {w + pad and its reflection partners}) of gp[(b, ho), wp, kh*C + c]
@@ -81,7 +157,7 @@ __global__ __launch_bounds__(NTP) void conv2d_fold_kernel(const ZsConv2dFold p) 
   const int cols = p.out_f32 ? p.C : p.fill_cols;
   const int groups = (cols + 7) / 8;
   const int64_t total = (int64_t)p.B * p.H_in * p.Wd * groups;
-  const int Wp = p.Wd + 2 * p.pad;
+  const int Wp = p.gp_rows > 0 ? p.gp_rows : p.Wd + 2 * p.pad;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int g = (int)(i % groups);
     const int64_t row = i / groups;
@@ -419,6 +495,16 @@ extern "C" int zs_conv2d_gather(const ZsConv2dGather* p, void* stream) {
   ZS_DT_OK(p);
   const int es = p->dtype == ZS_F32 ? 4 : 2;
   ZS_REQUIRE(p->B > 0 && p->H_in > 0 && p->H_out > 0 && p->Wd > 0 && p->C > 0 && p->k > 0 && p->stride > 0 && p->pad >= 0, "zs_conv2d_gather: sizes");
+  if (p->full) {
+    const int W_out = (p->Wd + 2 * p->pad - p->k) / p->stride + 1;
+    ZS_REQUIRE(p->ldo >= (int64_t)p->k * p->k * p->C && p->ldo % 8 == 0 && al16p(p->out) && W_out > 0, "zs_conv2d_gather(full): ldo %lld must be a multiple of 8 >= k*k*C", (long long)p->ldo);
+    ZS_REQUIRE(p->pad_mode != ZS_PAD_REFLECT || (p->pad < p->H_in && p->pad < p->Wd), "zs_conv2d_gather: Padding size should be less than the corresponding input dimension");
+    ZS_REQUIRE((p->stride * (p->H_out - 1) + p->k - 1 - p->pad) < p->H_in + p->pad, "zs_conv2d_gather: H_out too large");
+    const int64_t tot = (int64_t)p->B * p->H_out * W_out * (p->ldo / 8);
+    if (p->dtype == ZS_F32) hipLaunchKernelGGL(conv2d_im2col_kernel<float>, dim3(grid_for(tot)), dim3(NTP), 0, (hipStream_t)stream, *p, W_out);
+    else hipLaunchKernelGGL(conv2d_im2col_kernel<bf16_t>, dim3(grid_for(tot)), dim3(NTP), 0, (hipStream_t)stream, *p, W_out);
+    return zs_check_launch("zs_conv2d_gather.full");
+  }
   ZS_REQUIRE(p->ldo >= (int64_t)p->k * p->C && p->ldo % 8 == 0 && al16p(p->out), "zs_conv2d_gather: ldo %lld must be a multiple of 8 >= k*C", (long long)p->ldo);
   ZS_REQUIRE(p->pad_mode != ZS_PAD_REFLECT || p->pad < p->H_in, "zs_conv2d_gather: Padding size should be less than the corresponding input dimension");
   ZS_REQUIRE((p->stride * (p->H_out - 1) + p->k - 1 - p->pad) < p->H_in + p->pad, "zs_conv2d_gather: H_out too large");
@@ -433,6 +519,15 @@ extern "C" int zs_conv2d_fold(const ZsConv2dFold* p, void* stream) {
   ZS_REQUIRE(p && p->gp && p->out, "zs_conv2d_fold: null operand");
   ZS_DT_OK(p);
   ZS_REQUIRE(p->B > 0 && p->H_in > 0 && p->H_out > 0 && p->Wd > 0 && p->C > 0 && p->k > 0 && p->stride > 0 && p->pad >= 0, "zs_conv2d_fold: sizes");
+  if (p->full) {
+    const int W_out = (p->Wd + 2 * p->pad - p->k) / p->stride + 1;
+    ZS_REQUIRE(p->ldg >= (int64_t)p->k * p->k * p->C && W_out > 0, "zs_conv2d_fold(full): ldg");
+    ZS_REQUIRE(p->out_f32 || p->fill_cols == p->C, "zs_conv2d_fold(full): T-dtype output rows must be exactly C wide (no zero fill)");
+    const int64_t tot = (int64_t)p->B * p->H_in * p->Wd * p->C;
+    if (p->dtype == ZS_F32) hipLaunchKernelGGL(conv2d_col2im_kernel<float>, dim3(grid_for(tot)), dim3(NTP), 0, (hipStream_t)stream, *p, W_out);
+    else hipLaunchKernelGGL(conv2d_col2im_kernel<bf16_t>, dim3(grid_for(tot)), dim3(NTP), 0, (hipStream_t)stream, *p, W_out);
+    return zs_check_launch("zs_conv2d_fold.full");
+  }
   ZS_REQUIRE(p->ldg >= (int64_t)p->k * p->C && al16p(p->gp), "zs_conv2d_fold: ldg");
   if (!p->out_f32) ZS_REQUIRE(p->fill_cols >= p->C && p->fill_cols % 8 == 0 && p->fill_cols <= p->ldo && al16p(p->out) && p->ldo % 8 == 0, "zs_conv2d_fold: fill_cols / ldo");
   if ((p->C & 7) == 0) ZS_REQUIRE(p->ldg % 8 == 0, "zs_conv2d_fold: ldg alignment");

@@ -229,6 +229,10 @@ class ConvLayer(object):
         self.wd = torch.zeros(self.n_pad_d * self.ldw_d + SLACK, dtype=tdt, device=dev)
         self.bias_p = torch.zeros(self.Cout, dtype=torch.float32, device=dev) if (split2 and bias is not None) else None
         self.sid = next_sid()          # the side stream this layer's weight gradients always use
+        # stride-2 data gradient by output parity: position u of the padded domain only receives the taps j = u (mod 2), so the
+        # transposed convolution is two stride-1 correlations (even rows: taps 0, 2, 4; odd rows: taps 1, 3) over half the rows
+        # each -- half the MFMA work of feeding zero rows for the other taps (see dgrad)
+        self.parity = (stride == 2 and self.k > 1)
 
     def pack(self):
         c = self.ctx
@@ -236,8 +240,18 @@ class ConvLayer(object):
                       taps=self.k, co_split2=int(self.split2))
         L.call('zs_pack_weight', 'ZsPackWeight', c.stream, transpose=0, inner_pad=self.cin_pad, dst=L.ptr(self.wf),
                ldw=self.ldw, n_rows=self.n_pad, n_cols=self.ldw, **common)
-        L.call('zs_pack_weight', 'ZsPackWeight', c.stream, transpose=1, inner_pad=self.cout_pad, dst=L.ptr(self.wd),
-               ldw=self.ldw_d, n_rows=self.n_pad_d, n_cols=self.ldw_d, **common)
+        if self.parity:
+            # stride 2: taps in parity order [j = 0, 2, 4, .. | j = 1, 3, ..] (see dgrad): two strided views of the parameter
+            ne, no = (self.k + 1) // 2, self.k // 2
+            ev = dict(common, taps=ne, sj=2 * self.sj)
+            od = dict(common, taps=no, sj=2 * self.sj, W=L.ptr(self.w, self.sj))
+            L.call('zs_pack_weight', 'ZsPackWeight', c.stream, transpose=1, inner_pad=self.cout_pad, dst=L.ptr(self.wd),
+                   ldw=self.ldw_d, n_rows=self.n_pad_d, n_cols=ne * self.cout_pad, **ev)
+            L.call('zs_pack_weight', 'ZsPackWeight', c.stream, transpose=1, inner_pad=self.cout_pad, dst=L.ptr(self.wd),
+                   ldw=self.ldw_d, n_rows=self.n_pad_d, n_cols=no * self.cout_pad, col_offset=ne * self.cout_pad, **od)
+        else:
+            L.call('zs_pack_weight', 'ZsPackWeight', c.stream, transpose=1, inner_pad=self.cout_pad, dst=L.ptr(self.wd),
+                   ldw=self.ldw_d, n_rows=self.n_pad_d, n_cols=self.ldw_d, **common)
         if self.bias_p is not None:
             h = self.Cout // 2
             L.vec_copy(self.bias_p[:h], self.b, c.stream, src_stride=2)
@@ -285,6 +299,8 @@ class ConvLayer(object):
         stored; column 0 of `out` is channel n_off).  colsum_post: the column sums are taken of the stored value (after mask / add)."""
         c = self.ctx
         Tp = T_x + self.pad_l + self.pad_r
+        if self.parity:
+            return self._dgrad_parity(dY, Tp, out, out_f32, out_cols)
         N, n_pad = self.Cin, self.n_pad_d
         if n_cols is not None and (n_cols < self.Cin or n_off):
             N = n_cols
@@ -303,6 +319,23 @@ class ConvLayer(object):
         if colsum is not None:
             kw.update(colsum=colsum[0], colsum_ld=colsum[1], colsum_col0=colsum[2], colsum_post=int(colsum_post))
         L.call('zs_gemm_conv', 'ZsGemmConv', c.stream, **kw)
+        return Tp
+
+    def _dgrad_parity(self, dY, Tp, out, out_f32, out_cols):
+        """Stride-2 data gradient as two stride-1 launches (rows u = 2v and u = 2v + 1 of the padded domain).  `out` holds
+        Te = Tp rounded up to even rows per sample; the extra row of an odd domain receives no valid tap (zeros)."""
+        c = self.ctx
+        Te = Tp + (Tp & 1)
+        if out.T != Te:
+            raise ValueError('stride-2 dgrad: the output needs %d rows per sample (padded domain %d rounded up to even), got %d' % (Te, Tp, out.T))
+        ne = (self.k + 1) // 2
+        for par, taps in ((0, ne), (1, self.k // 2)):
+            kw = dict(dtype=c.dt, A=dY.ptr(), lda=dY.ld, a_batch_stride=dY.T * dY.ld, B=dY.B, T_in=dY.T, T_out=Te // 2, taps=taps,
+                      stride=1, pad_left=0, pad_mode=L.ZS_PAD_ZERO, gather=1, cin_pad=self.cout_pad,
+                      W=L.ptr(self.wd, par * ne * self.cout_pad), ldw=self.ldw_d, N=self.Cin, n_pad=self.n_pad_d, act=L.ZS_ACT_NONE,
+                      out=out.ptr(par * out.ld), ldc=2 * out.ld, out_cols=(out_cols if out_cols is not None else min(out.cols, rup(self.Cin, 32))),
+                      store_mode=L.ZS_STORE_ROWS, groups=1, out_f32=int(out_f32))
+            L.call('zs_gemm_conv', 'ZsGemmConv', c.stream, **kw)
         return Tp
 
     def wgrad(self, dY, X, accumulate=False, bias=True):

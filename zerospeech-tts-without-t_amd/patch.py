@@ -100,6 +100,27 @@ class _Conv2dLayer(object):
         self.gW.copy_(self.gWv.view(self.Cout, self.kt, self.C, self.kf).permute(0, 2, 3, 1))
 
 
+class _Conv2dFirstLayer(object):
+    """conv1 (C = 1): im2col along both axes -- all 25 taps of a position in ONE 128-byte K chunk -- and a Linear over those rows:
+    real parameter [Cout, 1, kf, kt] <-> virtual Linear weight [Cout, kt*kf].  (The H-only gather pads the 5 columns of every
+    W tap to a whole chunk: 12.8 x the input bytes and MFMA work, 16 % of a discriminator step.)"""
+
+    def __init__(self, ctx, W, b, gW, gb, pad_mode, name):
+        self.W, self.gW = W, gW
+        self.Cout, self.C, self.kf, self.kt = W.shape
+        self.Wv = torch.zeros(self.Cout, self.kt * self.kf * self.C, dtype=torch.float32, device=W.device)
+        self.gWv = torch.zeros_like(self.Wv)
+        self.layer = ConvLayer(ctx, self.Wv, b, self.gWv, gb, name=name)
+        self.pad_mode = pad_mode
+        self.full = True
+
+    def sync(self):      # virtual column (kt*kf + kf_i)*C + c  (zs_conv2d_gather(full): kh = time tap, kw = frequency tap)
+        self.Wv.view(self.Cout, self.kt, self.kf, self.C).copy_(self.W.permute(0, 3, 2, 1))
+
+    def flush(self):
+        self.gW.copy_(self.gWv.view(self.Cout, self.kt, self.kf, self.C).permute(0, 3, 2, 1))
+
+
 class _HeadLayer(object):
     """conv7 / conv_classify: an un-padded Conv2d whose kernel spans the whole [17, kt] map = a Linear on the flattened rows."""
 
@@ -129,8 +150,9 @@ class PatchEngine(object):
         self.ns, self.dp, self.n_class = float(ns), float(dp), n_class
         self.pad_mode = L.ZS_PAD_REFLECT if seg_len >= 64 else L.ZS_PAD_ZERO
         self.G = G
-        self.convs = [_Conv2dLayer(ctx, P['conv%d.weight' % i], P['conv%d.bias' % i], G['conv%d.weight' % i], G['conv%d.bias' % i],
-                                   self.pad_mode, 'pd_conv%d' % i) for i in range(1, 6)]
+        self.convs = [(_Conv2dFirstLayer if (i == 1 and P['conv1.weight'].shape[1] * 25 <= ctx.kc) else _Conv2dLayer)(
+            ctx, P['conv%d.weight' % i], P['conv%d.bias' % i], G['conv%d.weight' % i], G['conv%d.bias' % i], self.pad_mode, 'pd_conv%d' % i)
+            for i in range(1, 6)]
         w6 = P['conv6.weight']
         self.conv6 = ConvLayer(ctx, w6.view(w6.shape[0], w6.shape[1]), P['conv6.bias'], G['conv6.weight'].view(w6.shape[0], w6.shape[1]),
                                G['conv6.bias'], name='pd_conv6')
@@ -188,16 +210,25 @@ class PatchEngine(object):
     def _stat(self, key, what, B, C):
         return self.ctx.f32(self._name(key, what, B, C), B * C)
 
-    def _gather(self, x_ptr, ldx, x_f32, B, Hin, Hout, Wd, C, out):
+    def _gather(self, x_ptr, ldx, x_f32, B, Hin, Hout, Wd, C, out, full=False):
         c = self.ctx
         L.call('zs_conv2d_gather', 'ZsConv2dGather', c.stream, dtype=c.dt, x=x_ptr, ldx=ldx, x_f32=int(x_f32), out=out.ptr(), ldo=out.ld,
-               B=B, H_in=Hin, H_out=Hout, Wd=Wd, C=C, k=5, stride=2, pad=2, pad_mode=self.pad_mode)
+               B=B, H_in=Hin, H_out=Hout, Wd=Wd, C=C, k=5, stride=2, pad=2, pad_mode=self.pad_mode, full=int(full))
 
-    def _fold(self, gp, B, Hin, Hout, Wd, C, out_ptr, ldo, out_f32, fill_cols, add=None):
+    def _gathered(self, cl, name, B, H, W, C):
+        """The im2col buffer of layer `cl` for an input of [B, H, W, C]: rows (b, ho) x W with 5C columns, or -- first layer --
+        rows (b, ho) x W_out with all 25 C columns."""
+        Ho, Wo = _half(H), _half(W)
+        if getattr(cl, 'full', False):
+            return self.ctx.act(name, B * Ho, Wo, 25 * C, ld=cl.layer.cin_pad)
+        return self.ctx.act(name, B * Ho, W, 5 * C, ld=cl.layer.cin_pad)
+
+    def _fold(self, gp, B, Hin, Hout, Wd, C, out_ptr, ldo, out_f32, fill_cols, add=None, full=False):
         c = self.ctx
         L.call('zs_conv2d_fold', 'ZsConv2dFold', c.stream, dtype=c.dt, gp=gp.ptr(), ldg=gp.ld, out=out_ptr, ldo=ldo, out_f32=int(out_f32),
                fill_cols=fill_cols, add=(add.ptr() if add is not None else None), ldadd=(add.ld if add is not None else 0),
-               B=B, H_in=Hin, H_out=Hout, Wd=Wd, C=C, k=5, stride=2, pad=2, pad_mode=self.pad_mode)
+               B=B, H_in=Hin, H_out=Hout, Wd=Wd, C=C, k=5, stride=2, pad=2, pad_mode=self.pad_mode, gp_rows=(0 if full else gp.T),
+               full=int(full))
 
     def _f32_act(self, t, name, B, n):
         """fp32 tensor [B, n] -> Act [B, 1, n] in the compute dtype."""
@@ -222,8 +253,8 @@ class PatchEngine(object):
             if i < 5:
                 cl = self.convs[i]
                 Ho, Wo = _half(H), _half(W)
-                xh = c.act(self._name(key, 'xh%d' % i, B, H, W), B * Ho, W, 5 * C, ld=cl.layer.cin_pad)
-                self._gather(src_ptr, src_ld, src_f32, B, H, Ho, W, C, xh)
+                xh = self._gathered(cl, self._name(key, 'xh%d' % i, B, H, W), B, H, W, C)
+                self._gather(src_ptr, src_ld, src_f32, B, H, Ho, W, C, xh, full=getattr(cl, 'full', False))
                 Cout = cl.Cout
                 y = c.act(self._name(key, 'y%d' % i, B, H, W), B * Ho, Wo, Cout)
                 cl.layer.fwd(xh, out=y, act=LRELU, slope=ns)
@@ -329,7 +360,14 @@ class PatchEngine(object):
             Ld['layer'].dgrad(gzr, W, out, add_src=(Act(add.t, B * H, W, C, add.ld) if add is not None else None))
             return Act(out.t, B, H * W, C, out.ld), None
         lay = Ld['layer']
-        gp = c.act(self._name(key, tag + 'gp%d' % i, B), B * Ld['Ho'], W + 4, 5 * C)
+        if i == 0 and getattr(self.convs[0], 'full', False):          # first layer: Linear over the 25-tap rows, then col2im
+            dcol = c.act(self._name(key, tag + 'dcol', B), B * Ld['Ho'], Ld['Wo'], 25 * C)
+            lay.dgrad(gzr, Ld['Wo'], dcol)
+            dx = c.f32(self._name(key, tag + 'dx', B), B * H * W)
+            self._fold(dcol, B, H, Ld['Ho'], W, C, L.ptr(dx), 1, True, 0, full=True)
+            return None, dx[:B * H * W].view(B, H, W)
+        Wp = W + 4
+        gp = c.act(self._name(key, tag + 'gp%d' % i, B), B * Ld['Ho'], Wp + (Wp & 1), 5 * C)    # (even rows: stride-2 dgrad by parity)
         lay.dgrad(gzr, W, gp)
         if i == 0:
             dx = c.f32(self._name(key, tag + 'dx', B), B * H * W)
@@ -361,8 +399,8 @@ class PatchEngine(object):
             gbz = c.act(self._name(key, 'gbz%d' % i, B), B * Ho, Wo, Cout)
             gz_rows = Act(Ld['gz'].t, B * Ho, Wo, Cout, Ld['gz'].ld)
             if i < 5:
-                xh = c.act(self._name(key, 'gxh%d' % i, B), B * Ho, W, 5 * C, ld=Ld['layer'].cin_pad)
-                self._gather(src_ptr, src_ld, src_f32, B, H, Ho, W, C, xh)
+                xh = self._gathered(self.convs[i], self._name(key, 'gxh%d' % i, B), B, H, W, C)
+                self._gather(src_ptr, src_ld, src_f32, B, H, Ho, W, C, xh, full=getattr(self.convs[i], 'full', False))
                 Ld['layer'].fwd(xh, out=gbz, bias=False)
                 Ld['layer'].wgrad(gz_rows, xh, accumulate=True, bias=False)
             else:
