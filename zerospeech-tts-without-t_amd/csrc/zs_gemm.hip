@@ -1865,8 +1865,8 @@ WgradPlan wgrad_plan(const ZsGemmWgrad* p) {
     int64_t sp = (target + tiles - 1) / tiles;
     int64_t maxs = (M + 255) / 256;
     if (sp > maxs) sp = maxs;
-    if (sp > 64) sp = 64;
-    if (sp < 1) sp = 1;
+    if (sp > 1024) sp = 1024;        // (a one-tile output over millions of rows -- the first stage-2 layer: 64 x 25 over 2.1 M rows --
+    if (sp < 1) sp = 1;              //  needs hundreds of splits to fill the chip; the cap used to be 64: 64 workgroups, 1.2 ms)
     w.splits = (int)sp;
   }
   const int gran = w.p8 ? 64 : WK;
