@@ -529,6 +529,12 @@ int zs_row_moments(const ZsRowMoments* p, void* stream);
  *               xbar_a = -inv_dm*rstd*(gbar_y*S2/n + ga*dm*inv_dm*A2/n)                   (adjoint of xhat, as a gradient w.r.t. a)
  *             the adjoint of rstd, A3 = sum gbar_z*gz, is added to S2 (S2x) in the following `bwd` through the forward graph. */
 int zs_in2d_finalize(const float* s1, const float* q, float* mean, float* rstd, int64_t n_bc, int32_t T, float eps, void* stream);
+/* zs_in2d_stats: mean and rstd of the forward pass in ONE pass over y (instead of zs_row_moments twice + finalize: the rows
+ * of a 512-row slab are held in registers for a local mean and a local centred second moment; slabs are merged pairwise in a
+ * fixed order with Chan's update  M2 = M2a + M2b + d^2 na nb / n, so the result is as accurate as the two-pass form).
+ * y: [B][T] rows of ldy elements (T dtype), C % 8 == 0; partial: >= zs_row_moments_workspace(B, T, C) bytes. */
+int zs_in2d_stats(int32_t dtype, const void* y, int64_t ldy, int32_t B, int32_t T, int32_t C, float eps, float* mean, float* rstd,
+                  float* partial, size_t partial_bytes, void* stream);
 typedef struct {
   int32_t dtype;
   const void* y; int64_t ldy; void* a; int64_t lda;

@@ -297,6 +297,87 @@ __global__ void row_moments_finish_kernel(const ZsRowMoments p, int nslab) {
   if (p.s3) p.s3[i] = a3;
 }
 
+// ---- InstanceNorm2d forward statistics in one pass (zs_in2d_stats) ----------------------------------------------------------
+// grid (C/64, B, slabs of MOM_ROWS rows); thread (cg, rg): 8 channels of the slab's rows rg, rg + 32, ... (<= 16 rows, kept in
+// registers): thread-local mean, then thread-local centred second moment, merged over the 32 row groups in a fixed order.
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float nb, float meanb, float m2b) {
+  if (nb <= 0.f) return;
+  const float nt = n + nb, d = meanb - mean;
+  mean += d * (nb / nt);
+  m2 += m2b + d * d * (n * nb / nt);
+  n = nt;
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTP) void in2d_stats_kernel(const void* y_, int64_t ldy, int T_, int C, float* partial, int nslab) {
+  constexpr int RP = MOM_ROWS / 32;
+  __shared__ float red[2][32 * 64];
+  __shared__ float cnt[32];
+  const int tid = threadIdx.x, cg = tid & 7, rg = tid >> 3;
+  const int b = blockIdx.y, slab = blockIdx.z, c0 = blockIdx.x * 64 + cg * 8;
+  const bool cvalid = c0 < C;
+  const int t_lo = slab * MOM_ROWS, t_hi = min(T_, t_lo + MOM_ROWS);
+  Raw8<T> v[RP];
+  int nrow = 0;
+#pragma unroll
+  for (int i = 0; i < RP; ++i) {
+    const int t = t_lo + rg + 32 * i;
+    v[i].zero();
+    if (cvalid && t < t_hi) { v[i].ld((const T*)y_ + ((int64_t)b * T_ + t) * ldy + c0); ++nrow; }
+  }
+  float mean[8], m2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { mean[e] = 0.f; m2[e] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < RP; ++i) {
+    float f[8]; v[i].cvt(f);                                   // rows past the slab are zeros
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mean[e] += f[e];
+  }
+  const float inv = nrow > 0 ? 1.f / (float)nrow : 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) mean[e] *= inv;
+#pragma unroll
+  for (int i = 0; i < RP; ++i) {
+    if (t_lo + rg + 32 * i < t_hi) {
+      float f[8]; v[i].cvt(f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = f[e] - mean[e]; m2[e] += d * d; }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[0][rg * 64 + cg * 8 + e] = mean[e]; red[1][rg * 64 + cg * 8 + e] = m2[e]; }
+  if (cg == 0) cnt[rg] = (float)nrow;                          // (the same for every channel group of a row group)
+  __syncthreads();
+  if (tid < 64) {
+    float n = 0.f, mu = 0.f, q = 0.f;
+    for (int r = 0; r < 32; ++r) {
+      const float nb = cnt[r];
+      if (n == 0.f) { n = nb; mu = red[0][r * 64 + tid]; q = red[1][r * 64 + tid]; }
+      else chan_merge(n, mu, q, nb, red[0][r * 64 + tid], red[1][r * 64 + tid]);
+    }
+    const int cc = blockIdx.x * 64 + tid;
+    if (cc < C) {
+      float* o = partial + (((int64_t)b * nslab + slab) * 3) * C + cc;
+      o[0] = n; o[C] = mu; o[2 * (int64_t)C] = q;
+    }
+  }
+}
+
+__global__ void in2d_stats_finish_kernel(const float* partial, int B, int C, int nslab, float eps, float* mean, float* rstd) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * C) return;
+  const int b = (int)(i / C), c = (int)(i % C);
+  float n = 0.f, mu = 0.f, q = 0.f;
+  for (int s = 0; s < nslab; ++s) {
+    const float* o = partial + ((int64_t)b * nslab + s) * 3 * C + c;
+    if (n == 0.f) { n = o[0]; mu = o[C]; q = o[2 * (int64_t)C]; }
+    else chan_merge(n, mu, q, o[0], o[C], o[2 * (int64_t)C]);
+  }
+  mean[i] = mu;
+  rstd[i] = 1.0f / sqrtf(q / n + eps);
+}
+
 __global__ void in2d_finalize_kernel(const float* s1, const float* q, float* mean, float* rstd, int64_t n, float invT, float eps) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -562,6 +643,24 @@ extern "C" int zs_row_moments(const ZsRowMoments* p, void* stream) {
   const int64_t n = (int64_t)p->B * p->C;
   hipLaunchKernelGGL(row_moments_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p, nslab);
   return zs_check_launch("zs_row_moments.finish");
+}
+
+extern "C" int zs_in2d_stats(int32_t dtype, const void* y, int64_t ldy, int32_t B, int32_t T, int32_t C, float eps, float* mean, float* rstd,
+                             float* partial, size_t partial_bytes, void* stream) {
+  ZS_REQUIRE(y && mean && rstd && partial, "zs_in2d_stats: null operand");
+  ZS_REQUIRE(dtype == ZS_F32 || dtype == ZS_BF16, "zs_in2d_stats: bad dtype");
+  ZS_REQUIRE(B > 0 && T > 0 && C > 0 && C % 8 == 0 && al16p(y) && ldy % 8 == 0, "zs_in2d_stats: sizes / alignment (C %% 8 == 0)");
+  ZS_REQUIRE(partial_bytes >= zs_row_moments_workspace(B, T, C), "zs_in2d_stats: workspace too small");
+  const int nslab = (T + MOM_ROWS - 1) / MOM_ROWS;
+  ZS_REQUIRE(nslab <= 65535 && B <= 65535, "zs_in2d_stats: grid too large");
+  dim3 grid((unsigned)((C + 63) / 64), (unsigned)B, (unsigned)nslab);
+  if (dtype == ZS_F32) hipLaunchKernelGGL(in2d_stats_kernel<float>, grid, dim3(NTP), 0, (hipStream_t)stream, y, ldy, T, C, partial, nslab);
+  else hipLaunchKernelGGL(in2d_stats_kernel<bf16_t>, grid, dim3(NTP), 0, (hipStream_t)stream, y, ldy, T, C, partial, nslab);
+  int rc = zs_check_launch("zs_in2d_stats");
+  if (rc) return rc;
+  const int64_t n = (int64_t)B * C;
+  hipLaunchKernelGGL(in2d_stats_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, B, C, nslab, eps, mean, rstd);
+  return zs_check_launch("zs_in2d_stats.finish");
 }
 
 extern "C" int zs_in2d_finalize(const float* s1, const float* q, float* mean, float* rstd, int64_t n_bc, int32_t T, float eps, void* stream) {

@@ -266,11 +266,10 @@ class PatchEngine(object):
                 layer, xin = self.conv6, prev_a
             Tn = Ho * Wo
             yv = Act(y.t, B, Tn, Cout, y.ld)
-            s1, q = self._stat(key, 's1_%d' % i, B, Cout), self._stat(key, 'q_%d' % i, B, Cout)
             mean, rstd = self._stat(key, 'mean_%d' % i, B, Cout), self._stat(key, 'rstd_%d' % i, B, Cout)
-            self._moments(yv, B, Tn, Cout, s1)
-            self._moments(yv, B, Tn, Cout, s1=self._stat(key, 'tmp_%d' % i, B, Cout), s2=q, v=yv, center_sum=s1)
-            L.check(L.lib().zs_in2d_finalize(L.ptr(s1), L.ptr(q), L.ptr(mean), L.ptr(rstd), B * Cout, Tn, EPS_IN, c.stream), 'zs_in2d_finalize')
+            ws = self._ws(B, Tn, Cout)
+            L.check(L.lib().zs_in2d_stats(c.dt, yv.ptr(), yv.ld, B, Tn, Cout, EPS_IN, L.ptr(mean), L.ptr(rstd), L.ptr(ws), ws.numel() * 4, c.stream),
+                    'zs_in2d_stats')                                    # one pass over y (was: two moment passes + finalize)
             dm = None
             if dp > 0.0:
                 if masks is not None and masks[i] is not None:
