@@ -463,7 +463,7 @@ def parity_record(enc, dec, dev, B=256):
     return out
 
 
-GL_TRAFFIC_FILE = 'r02_resynth_pmc_traffic.json'
+GL_TRAFFIC_FILE = 'r03_resynth_pmc_traffic.json'
 
 _JSON_FD = None
 
@@ -616,7 +616,7 @@ def main():
     }
     peak = 2500.0 if args.dtype == 'bf16' else 157.3
     traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+    tpath = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
     if args.dtype == 'bf16' and B == 256 and os.path.exists(tpath):
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); counters cannot be read from inside the process
@@ -645,6 +645,25 @@ def main():
         # secondary records, all outside the timed region: parity of the benchmarked bf16 model, BASELINE configs 4 and 5
         ke.uninstall()
         sec = {}
+        if not args.host_input and ae.use_graph:
+            # the PCIe-inclusive rate (the reference copies every batch from host memory): the same step with the
+            # next batch fetched from pinned host memory by a branch of the captured step (trainer.HostFedStep); never the headline
+            class _HostBatches(object):
+                def __init__(self, c_host, x_host):
+                    self.c, self.x = c_host, x_host
+
+                def __next__(self):
+                    return self.c, self.x
+            hf = ae.host_feeder(_HostBatches(c.cpu(), x.cpu()))
+            for _ in range(4):
+                next(hf)
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            for _ in range(10):
+                next(hf)
+            torch.cuda.synchronize()
+            out['host_input_ms_per_step'] = 1e3 * (time.perf_counter() - th) / 10
+            log('secondary: batch from host memory every step: %.2f ms/step' % out['host_input_ms_per_step'])
         sec['parity_bf16_vs_fp32'] = parity_record(enc, dec, dev, B=B)
         log('secondary: parity %s' % json.dumps(sec['parity_bf16_vs_fp32']))
         out['mbv_bit_mismatch_rate'] = sec['parity_bf16_vs_fp32']['mbv_bit_mismatch_rate']

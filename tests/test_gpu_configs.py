@@ -340,6 +340,28 @@ def test_config1_main_train_ae_synthetic(dev, tmp_path, monkeypatch, capsys):
     assert os.path.exists(str(tmp_path / 'ck' / 'model.pth-ae-4'))
 
 
+def test_load_model_takes_the_target_classifier_from_clf_path(dev, tmp_path):
+    """trainer.py:157-161: with clf_path the TargetClassifier comes from ANOTHER checkpoint (tag `[target_classifier_another]`),
+    everything else from model_path."""
+    from zs_amd.hps import make_hps
+    from zs_amd.trainer import Trainer
+    hps = make_hps(enc_size=8, emb_size=32, n_speakers=4, n_target_speakers=2, max_to_keep=5)
+    trs = []
+    for seed in (1, 2):
+        torch.manual_seed(seed)
+        tr = Trainer(hps, None, hps.g_mode, hps.enc_mode, log_dir=str(tmp_path / 'log'), dtype='fp32', device=dev)
+        tr.save_model(str(tmp_path / ('m%d.pth' % seed)), 's2', 1)
+        trs.append(tr)
+    tr3 = Trainer(hps, None, hps.g_mode, hps.enc_mode, log_dir=str(tmp_path / 'log'), dtype='fp32', device=dev)
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        tr3.load_model(str(tmp_path / 'm1.pth-s2-1'), 'encoder, decoder, generator, target_classifier', clf_path=str(tmp_path / 'm2.pth-s2-1'))
+    assert '[target_classifier_another]' in buf.getvalue() and '[encoder], [decoder], [generator]' in buf.getvalue()
+    assert torch.equal(tr3.TargetClassifier.flat_params()[0], trs[1].TargetClassifier.flat_params()[0])
+    assert not torch.equal(tr3.TargetClassifier.flat_params()[0], trs[0].TargetClassifier.flat_params()[0])
+    assert torch.equal(tr3.Encoder.flat_params()[0], trs[0].Encoder.flat_params()[0])
+
+
 def test_pretrain_c_and_train_loops_run(dev, tmp_path, monkeypatch):
     """The speaker-classifier modes of Trainer.train (trainer.py:349-465) run end to end on a small model."""
     from zs_amd.dataloader import DataLoader, SyntheticDataset
