@@ -336,6 +336,25 @@ def test_batched_encode_resynthesis_64_utterances(cv, tmp_path):
     wavs_d = cv.spectrogram2wav_batch(decs_d[:16], n_iter=20, do_trim=False)
     for w, w2 in zip(wavs, wavs_d):
         assert np.array_equal(w, w2)
+    # the whole pipeline as ONE enqueue (resynth_batch), from host arrays and from utterances already resident in HBM:
+    # the same encodings and waveforms as encode_batch + spectrogram2wav_batch on the same utterances and noise
+    for do_trim in (False, True):
+        store.clear()
+        e16, d16 = cv.encode_batch(specs[:16], tr, 128, decode_speakers=spk[:16], noise_fn=noise_fn)
+        w16 = cv.spectrogram2wav_batch(d16, n_iter=20, do_trim=do_trim)
+        for src in (specs[:16], [torch.from_numpy(s).cuda() for s in specs[:16]]):
+            store.clear()
+            e_r, w_r = cv.resynth_batch(src, tr, 128, spk[:16], n_iter=20, do_trim=do_trim, noise_fn=noise_fn)
+            assert len(e_r) == 16 and len(w_r) == 16
+            for a, b, w, w2 in zip(e16, e_r, w16, w_r):
+                assert np.array_equal(a, b) and w.dtype == np.float32 and np.array_equal(w, w2)
+    # a short utterance (< MIN_LEN frames, zero-padded by the fragment rule) resident on the device takes the same path
+    short = [np.clip(rng.rand(5, 513).astype(np.float32), 1e-8, 1), specs[0]]
+    store.clear()
+    e_h, _ = cv.encode_batch(short, tr, 128, decode_speakers=[0, 1], noise_fn=noise_fn)
+    store.clear()
+    e_d, _ = cv.encode_batch([torch.from_numpy(s).cuda() for s in short], tr, 128, decode_speakers=[0, 1], noise_fn=noise_fn)
+    assert all(np.array_equal(a, b) for a, b in zip(e_h, e_d)) and e_h[0].shape[0] == 1
 
 
 def test_encode_batch_draws_fresh_noise_and_decodes_its_own_bits(cv, tmp_path):

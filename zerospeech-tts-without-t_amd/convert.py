@@ -125,23 +125,10 @@ def trim_bounds(mse, n, top_db=60, hop_length=TRIM_HOP):
     return int(nz[0]) * hop_length, min(n, (int(nz[-1]) + 1) * hop_length)
 
 
-def spectrogram2wav_batch(mags_tf, n_iter=None, do_trim=True):
-    """Batched spectrogram2wav (convert.py:55-62): list of [T_i, 513] normalised magnitudes -> list of float32 wavs.
-    One padded host buffer, one H2D copy, one de-normalisation launch, one zs_griffin_lim call, one de-emphasis launch, one
-    D2H copy; only librosa.effects.trim (restated) runs per utterance on the host."""
-    dev = _device()
+def _enqueue_vocoder(t, lens, n_iter, do_trim, dev):
+    """t: normalised magnitudes [n, T_max, 513] fp32 on the device.  Enqueues convert.py:55-62 and returns the function that
+    waits for it and cuts the waveforms (librosa.effects.trim restated on device-computed frame statistics)."""
     st = torch.cuda.current_stream(dev).cuda_stream
-    lens = [int(m.shape[0]) for m in mags_tf]
-    n, Tm = len(lens), max(lens)
-    if all(torch.is_tensor(m) and m.is_cuda for m in mags_tf):          # decoder outputs still on the device (encode_batch(to_host=False))
-        t = torch.zeros(n, Tm, 513, dtype=torch.float32, device=dev)
-        for i, m in enumerate(mags_tf):
-            t[i, :lens[i]] = m
-    else:
-        host = np.zeros((n, Tm, 513), dtype=np.float32)
-        for i, m in enumerate(mags_tf):
-            host[i, :lens[i]] = np.asarray(m.cpu() if torch.is_tensor(m) else m, dtype=np.float32)
-        t = torch.from_numpy(host).to(dev)
     amp = torch.empty_like(t)
     L.check(L.lib().zs_gl_denormalize(L.ptr(t), L.ptr(amp), t.numel(), st), 'zs_gl_denormalize')     # convert.py:56-58
     wav, lengths, lens = griffin_lim_batch(None, n_iter=n_iter, device=dev, mag_padded=(amp, lens))
@@ -155,19 +142,42 @@ def spectrogram2wav_batch(mags_tf, n_iter=None, do_trim=True):
                 'zs_gl_frame_mse')
         mse_h = _to_host(mse)
     w_h = _to_host(wav)
-    torch.cuda.current_stream(dev).synchronize()
-    w = w_h.numpy()
-    out = []
-    for i, T in enumerate(lens):
-        y = w[i, :200 * (T - 1)]
-        if do_trim:
-            if mse_h is not None:
-                a, b = trim_bounds(mse_h[i, :1 + len(y) // TRIM_HOP].numpy(), len(y))
-                y = y[a:b]
-            else:
-                y, _ = trim(y)
-        out.append(np.asarray(y, dtype=np.float32))
-    return out
+
+    def finish():
+        torch.cuda.current_stream(dev).synchronize()
+        w = w_h.numpy()
+        out = []
+        for i, T in enumerate(lens):
+            y = w[i, :200 * (T - 1)]
+            if do_trim:
+                if mse_h is not None:
+                    a, b = trim_bounds(mse_h[i, :1 + len(y) // TRIM_HOP].numpy(), len(y))
+                    y = y[a:b]
+                else:
+                    y, _ = trim(y)
+            out.append(np.asarray(y, dtype=np.float32))
+        return out
+    return finish
+
+
+def spectrogram2wav_batch(mags_tf, n_iter=None, do_trim=True):
+    """Batched spectrogram2wav (convert.py:55-62): list of [T_i, 513] normalised magnitudes -> list of float32 wavs.
+    One padded buffer, one H2D copy (unless the magnitudes are on the device already), one de-normalisation launch, one
+    zs_griffin_lim call, one de-emphasis launch, one D2H copy; librosa.effects.trim (restated) from frame statistics computed on
+    the device."""
+    dev = _device()
+    lens = [int(m.shape[0]) for m in mags_tf]
+    n, Tm = len(lens), max(lens)
+    if all(torch.is_tensor(m) and m.is_cuda for m in mags_tf):          # decoder outputs still on the device (encode_batch(to_host=False))
+        t = torch.zeros(n, Tm, 513, dtype=torch.float32, device=dev)
+        for i, m in enumerate(mags_tf):
+            t[i, :lens[i]] = m
+    else:
+        host = np.zeros((n, Tm, 513), dtype=np.float32)
+        for i, m in enumerate(mags_tf):
+            host[i, :lens[i]] = np.asarray(m.cpu() if torch.is_tensor(m) else m, dtype=np.float32)
+        t = torch.from_numpy(host).to(dev)
+    return _enqueue_vocoder(t, lens, n_iter, do_trim, dev)()
 
 
 def spectrogram2wav(mag, n_iter=None):
@@ -293,17 +303,21 @@ def _pool():
 
 
 def _stage_rows(arrays, dev):
-    """list of [T_i, C] arrays on the host -> (device fp32 tensor [sum T_i + 1, C] whose LAST row is zeros, row offsets).
-    One pass over the bytes into a pinned buffer (torch's caching host allocator recycles it between calls), several threads,
-    then ONE asynchronous H2D copy at the link rate -- a pageable .to(device) of the same bytes is 3-4 x slower."""
+    """list of [T_i, C] arrays -> (device fp32 tensor [sum T_i + 1, C] whose LAST row is zeros, row offsets).
+    Host arrays: one pass over the bytes into a pinned buffer (torch's caching host allocator recycles it between calls),
+    several threads, then ONE asynchronous H2D copy at the link rate -- a pageable .to(device) of the same bytes is 3-4 x
+    slower.  Utterances already resident in HBM (torch tensors on `dev`): one concatenation on the device, no host pass."""
     C = int(arrays[0].shape[1])
     offs = np.concatenate(([0], np.cumsum([int(a.shape[0]) for a in arrays]))).astype(np.int64)
     total = int(offs[-1])
+    if all(torch.is_tensor(a) and a.is_cuda for a in arrays):
+        return torch.cat([a.to(dev, torch.float32) for a in arrays] + [torch.zeros(1, C, dtype=torch.float32, device=dev)], dim=0), offs
     host = torch.empty(total + 1, C, dtype=torch.float32, pin_memory=True)
     host[total].zero_()
 
     def put(i):
-        host[offs[i]:offs[i + 1]].copy_(torch.from_numpy(np.ascontiguousarray(arrays[i], dtype=np.float32)))
+        a = arrays[i]
+        host[offs[i]:offs[i + 1]].copy_(a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)))
     list(_pool().map(put, range(len(arrays))))
     return host.to(dev, non_blocking=True), offs
 
@@ -315,21 +329,30 @@ def _to_host(t):
     return h
 
 
-def encode_batch(specs, trainer, seg_len, decode_speakers=None, noise_fn=None, max_batch=256, to_host=True):
-    """Batched encode()/convert() for many utterances: the same fragments the reference would send through the network one by
-    one (convert.py:151-165), as a few large batches on the GPU.
-    specs: list of [T_i, 513] arrays.  decode_speakers: optional list of target speaker ids -> also returns the decoded
-    spectrograms (enc_only path of convert()).  noise_fn(n_frag, T', E) -> Gumbel noise [n, T', E, 2] or None makes the
-    stochastic discretiser reproducible (called once per batch; T' = encoded frames of the longest member).  Returns
-    (encodings list, decoded list or None); to_host=False leaves the decoded spectrograms on the device (torch tensors
-    [T_out, 513]) for spectrogram2wav_batch."""
+def _t8(n):
+    return ((((n + 1) // 2 + 1) // 2) + 1) // 2
+
+
+class _Enqueued(object):
+    """What _enqueue_encode leaves behind: nothing here has been waited for."""
+    __slots__ = ('n_utt', 'chunks', 'enc_host', 'dec_dev', 'dec_host', 'enc_done', 'dev')
+
+
+def _enqueue_encode(specs, trainer, seg_len, decode_speakers, noise_fn, max_batch, dec_to_host):
+    """Fragment rule + every Encoder / Decoder launch of a batch of utterances, WITHOUT a host synchronisation: the caller decides
+    what else to put on the stream (the vocoder) before it waits."""
     trainer.set_eval()
     enc, dec = trainer.Encoder, trainer.Decoder
     dev = trainer.device
     items = []                                            # (utt, order, start, stop, truncate)
     padded = []
     for u, spec in enumerate(specs):
-        spec, was_padded = _pad_min(np.asarray(spec, dtype=np.float32))
+        if torch.is_tensor(spec) and spec.is_cuda:
+            was_padded = spec.shape[0] < MIN_LEN
+            if was_padded:
+                spec = torch.nn.functional.pad(spec, (0, 0, 0, MIN_LEN - spec.shape[0]))
+        else:
+            spec, was_padded = _pad_min(np.asarray(spec, dtype=np.float32))
         padded.append(spec)
         if len(spec) <= seg_len:
             items.append((u, 0, 0, len(spec), (MIN_LEN // 8) if was_padded else None))
@@ -347,8 +370,8 @@ def encode_batch(specs, trainer, seg_len, decode_speakers=None, noise_fn=None, m
     # every utterance goes to the device once, whole; the fragments are gathered there (row index tables, a few hundred KB)
     rows, offs = _stage_rows(padded, dev)
     zero_row = int(offs[-1])
-    enc_out, dec_out = {}, {}
-    pending = []                                          # (chunk, lengths, host encodings, spectrograms): one host sync at the end
+    q = _Enqueued()
+    q.n_utt, q.dev, q.chunks, q.enc_host, q.dec_dev, q.dec_host = len(specs), dev, [], [], [], []
     for chunk, ragged in chunks:
         lens = [b - a for (_, _, a, b, _) in chunk]
         Tm = max(lens)
@@ -356,40 +379,104 @@ def encode_batch(specs, trainer, seg_len, decode_speakers=None, noise_fn=None, m
         for i, (u, _, a, b, _) in enumerate(chunk):
             idx[i, :b - a] = np.arange(offs[u] + a, offs[u] + b)
         x = rows[torch.from_numpy(idx).to(dev, non_blocking=True)]                                     # [n, Tm, 513]
-        Tp = ((((Tm + 1) // 2 + 1) // 2) + 1) // 2
-        G = noise_fn(len(chunk), Tp, enc.enc_size) if noise_fn is not None else None
+        G = noise_fn(len(chunk), _t8(Tm), enc.enc_size) if noise_fn is not None else None
         act, _ = enc(x.permute(0, 2, 1), G=G, lengths=(lens if ragged else None))
         xd = None
         if decode_speakers is not None:
             ch = torch.tensor([decode_speakers[u] for (u, _, _, _, _) in chunk], dtype=torch.int64)
-            lens_p = [((((n + 1) // 2 + 1) // 2) + 1) // 2 for n in lens]
-            xd = dec(act, ch.to(dev, non_blocking=True), lengths=(lens_p if ragged else None)).permute(0, 2, 1)
-            if to_host:
-                xd = _to_host(xd.contiguous())
-        pending.append((chunk, lens, _to_host(act.permute(0, 2, 1).contiguous()), xd))
-    torch.cuda.current_stream(dev).synchronize()
-    from . import layers
-    layers.check_status(dev)                                  # synchronised: a timed-out GRU pass raises here
-    for chunk, lens, e_host, xd in pending:
-        e = e_host.numpy()
-        if xd is not None and to_host:
-            xd = xd.numpy()
+            lens_p = [_t8(n) for n in lens]
+            xd = dec(act, ch.to(dev, non_blocking=True), lengths=(lens_p if ragged else None)).permute(0, 2, 1).contiguous()
+        q.chunks.append((chunk, lens))
+        q.enc_host.append(_to_host(act.permute(0, 2, 1).contiguous()))
+        q.dec_dev.append(xd)
+        q.dec_host.append(_to_host(xd) if (xd is not None and dec_to_host) else None)
+    q.enc_done = torch.cuda.Event()
+    q.enc_done.record(torch.cuda.current_stream(dev))
+    return q
+
+
+def _assemble(q, want_dec):
+    """Per-utterance encodings (and decoded spectrograms: 'host', 'device' or None) from the chunk outputs, in fragment order.
+    The caller has waited for the copies."""
+    enc_out, dec_out = {}, {}
+    for ci, (chunk, lens) in enumerate(q.chunks):
+        e = q.enc_host[ci].numpy()
+        xd = None
+        if want_dec == 'host':
+            xd = q.dec_host[ci].numpy()
+        elif want_dec == 'device':
+            xd = q.dec_dev[ci]
         for i, (u, k, _, _, trunc) in enumerate(chunk):
-            tp = ((((lens[i] + 1) // 2 + 1) // 2) + 1) // 2
+            tp = _t8(lens[i])
             enc_out[(u, k)] = e[i][:trunc] if trunc is not None else e[i][:tp]
             if xd is not None:
                 dec_out[(u, k)] = xd[i][:8 * tp]
     by_utt = {}
     for (u, k) in enc_out:
         by_utt.setdefault(u, []).append(k)
-    encs, decs = [], ([] if decode_speakers is not None else None)
-    for u in range(len(specs)):
+    encs, decs = [], ([] if want_dec else None)
+    for u in range(q.n_utt):
         ks = sorted(by_utt[u])
         encs.append(np.concatenate([enc_out[(u, k)] for k in ks], axis=0))
         if decs is not None:
             parts = [dec_out[(u, k)] for k in ks]
-            decs.append(np.concatenate(parts, axis=0) if to_host else (parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)))
+            decs.append(np.concatenate(parts, axis=0) if want_dec == 'host' else (parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)))
     return encs, decs
+
+
+def encode_batch(specs, trainer, seg_len, decode_speakers=None, noise_fn=None, max_batch=256, to_host=True):
+    """Batched encode()/convert() for many utterances: the same fragments the reference would send through the network one by
+    one (convert.py:151-165), as a few large batches on the GPU.
+    specs: list of [T_i, 513] arrays (host arrays, or torch tensors already on the device).  decode_speakers: optional list of
+    target speaker ids -> also returns the decoded spectrograms (enc_only path of convert()).  noise_fn(n_frag, T', E) -> Gumbel
+    noise [n, T', E, 2] or None makes the stochastic discretiser reproducible (called once per batch; T' = encoded frames of the
+    longest member).  Returns (encodings list, decoded list or None); to_host=False leaves the decoded spectrograms on the
+    device (torch tensors [T_out, 513]) for spectrogram2wav_batch."""
+    q = _enqueue_encode(specs, trainer, seg_len, decode_speakers, noise_fn, max_batch, dec_to_host=to_host)
+    torch.cuda.current_stream(q.dev).synchronize()
+    from . import layers
+    layers.check_status(q.dev)                                # synchronised: a timed-out GRU pass raises here
+    return _assemble(q, None if decode_speakers is None else ('host' if to_host else 'device'))
+
+
+def resynth_batch(specs, trainer, seg_len, speakers, n_iter=None, do_trim=True, noise_fn=None, max_batch=256):
+    """test_encode + convert(enc_only) + spectrogram2wav for a batch of utterances as ONE enqueue (convert.py:151-165, 55-62):
+    the fragments' Encoder / Decoder launches, the gather of the decoded fragments into the vocoder's padded [n, T_max, 513]
+    input (one index kernel on the device), de-normalisation, the Griffin-Lim loop, de-emphasis, the trim statistics and the
+    D2H copies go onto the stream back to back; the host assembles the encodings while the vocoder runs and waits ONCE.
+    Returns (encodings list, wav list) -- the same values as encode_batch(...) followed by spectrogram2wav_batch(...)."""
+    q = _enqueue_encode(specs, trainer, seg_len, speakers, noise_fn, max_batch, dec_to_host=False)
+    dev = q.dev
+    # row table of all decoded fragments + a zero row; utterance u's frames are its fragments' rows in order
+    bases, total = [], 0
+    for ci, (chunk, lens) in enumerate(q.chunks):
+        bases.append(total)
+        total += q.dec_dev[ci].shape[0] * q.dec_dev[ci].shape[1]
+    frag_rows = {}
+    for ci, (chunk, lens) in enumerate(q.chunks):
+        ld = q.dec_dev[ci].shape[1]
+        for i, (u, k, _, _, _) in enumerate(chunk):
+            frag_rows.setdefault(u, []).append((k, bases[ci] + i * ld, 8 * _t8(lens[i])))
+    ulens = []
+    for u in range(q.n_utt):
+        frag_rows[u].sort()
+        ulens.append(sum(n for (_, _, n) in frag_rows[u]))
+    Tm = max(ulens)
+    idx = np.full((q.n_utt, Tm), total, dtype=np.int64)
+    for u in range(q.n_utt):
+        at = 0
+        for (_, r0, n) in frag_rows[u]:
+            idx[u, at:at + n] = np.arange(r0, r0 + n)
+            at += n
+    table = torch.cat([x.reshape(-1, x.shape[2]) for x in q.dec_dev] + [torch.zeros(1, q.dec_dev[0].shape[2], dtype=q.dec_dev[0].dtype, device=dev)], dim=0)
+    t = table[torch.from_numpy(idx).to(dev, non_blocking=True)].float()                               # [n, Tm, 513]
+    fin = _enqueue_vocoder(t, ulens, n_iter, do_trim, dev)
+    q.enc_done.synchronize()                                  # the encodings are on the host; the vocoder is still running
+    encs, _ = _assemble(q, None)
+    wavs = fin()
+    from . import layers
+    layers.check_status(dev)
+    return encs, wavs
 
 
 def write_wav(path, wav, sr):
