@@ -305,6 +305,7 @@ def resynth_record(args, rank, world, dev, steps, warmup, cpu=True):
     out_frames = int(sum(d.shape[0] for d in decs))
     n_utt = len(lens_all)
     value = n_utt * steps / dt
+    log('resynth: Griffin-Lim per step (ms): ' + ' '.join('%.2f' % g for g in gl_ms))
     gl = sum(gl_ms) / len(gl_ms) * 1e-3
     gl_traffic = None
     tpath = os.path.join(ROOT, 'profiles', GL_TRAFFIC_FILE)
@@ -325,7 +326,8 @@ def resynth_record(args, rank, world, dev, steps, warmup, cpu=True):
            'host_input_ms_per_step': 1e3 * dt_host, 'encode_decode_ms': 1e3 * dt_enc, 'griffin_lim_ms': 1e3 * gl,
            'roofline': {'bound': 'hbm', 'achieved': by / launch_s / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': by / launch_s / 8e12,
                         'traffic': gl_traffic, 'traffic_unit': 'bytes/launch (committed rocprofv3 --pmc passes of this command)',
-                        'kernel': 'gl_iter_kernel (one fused Griffin-Lim iteration per launch, %d launches per batch)' % (n_iter + 1),
+                        'kernel': 'gl_iter_kernel (one fused Griffin-Lim iteration of ALL utterances = one "launch" here; issued as up to 3 '
+                                  'concurrent launches over utterance ranges on independent streams, %d iterations per batch)' % (n_iter + 1),
                         'avg_launch_ms': 1e3 * launch_s, 'algorithmic_bytes_per_launch': by,
                         'fft_tflops': fl / gl / 1e12, 'fft_frac_of_fp32_vector_peak': fl / gl / 1e12 / 157.3}}
     if cpu:

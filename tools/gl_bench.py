@@ -31,8 +31,12 @@ def run(**kw):
 tiles = [int(t) for t in os.environ.get('GL_TILES', '6,8,10,12,14,18,26').split(',')]
 from zs_amd import _lib as L  # noqa: E402
 L.set_option('gl_prefetch', int(os.environ.get('GL_PREFETCH', '1')))
-for kw in [dict(impl='split')] + [dict(impl='fused', tile_frames=t) for t in tiles]:
+chains = [int(c) for c in os.environ.get('GL_CHAINS', '3').split(',')]
+for kw in [dict(impl='split')] + [dict(impl='fused', tile_frames=t, chains=c) for c in chains for t in tiles]:
+    label = dict(kw)
+    if 'chains' in kw:
+        L.set_option('gl_chains', kw.pop('chains'))
     dt = min(run(**kw) for _ in range(3))
     # 2 real 1024-point transforms per frame and iteration, 5 N log2 N / 2 flops each (N = 1024, real input)
     fl = frames * (2 * n_iter + 1) * 2.5 * 1024 * 10
-    print('%-40s %8.2f ms  %7.1f utt/s  %9.0f frames/s  %6.2f TFLOP/s' % (kw, dt * 1e3, 64 / dt, frames / dt, fl / dt / 1e12), flush=True)
+    print('%-52s %8.2f ms  %7.1f utt/s  %9.0f frames/s  %6.2f TFLOP/s' % (label, dt * 1e3, 64 / dt, frames / dt, fl / dt / 1e12), flush=True)

@@ -24,6 +24,7 @@
 // zs_griffin_lim runs the whole loop (n_iter launches ping-ponging two spectrogram buffers + the final inverse pass) from
 // one C call.  The older one-transform-per-workgroup kernels (zs_vocoder.hip) remain as the variant the tests compare with.
 #include <atomic>
+#include <chrono>
 #include <mutex>
 
 #include "zs_common.h"
@@ -419,7 +420,7 @@ int gl_check(const ZsGlIter* p, const char* what) {
 
 }  // namespace
 
-// "gl_prefetch" knob of zs_set_option
+// "gl_prefetch" / "gl_chains" knobs of zs_set_option
 int zs_gl_prefetch_option(int value) { return g_gl_prefetch.exchange(value ? 1 : 0, std::memory_order_relaxed); }
 
 extern "C" int zs_gl_iter(const ZsGlIter* p, void* stream) {
@@ -431,20 +432,131 @@ extern "C" int zs_gl_iter(const ZsGlIter* p, void* stream) {
   return gl_launch(p, p->spec_in, p->spec_out, (hipStream_t)stream);
 }
 
+namespace {
+
+// The iterations of different utterances are independent, and a launch over ALL utterances ends in a partly filled last round of
+// workgroups (64 utterances of 200..700 frames: 1130 tiles of 26 frames on 512 resident workgroups = 2.2 rounds; 22-frame tiles
+// take 39.5 ms where 23-frame tiles take 32.0).  zs_griffin_lim therefore runs the loop as `gl_chains` independent launch chains
+// (contiguous utterance ranges of equal utterance count) on side streams: a chain's partial rounds are filled
+// by the other chains' workgroups -- no iteration-wide barrier across utterances that do not depend on each other.
+constexpr int GL_MAX_CHAINS = 4, GL_CANDIDATES = 10;
+struct GlSide {
+  hipStream_t s[GL_MAX_CHAINS] = {};
+  int n = 0;                                   // mutually concurrent streams found
+  hipEvent_t fork = nullptr, join[GL_MAX_CHAINS] = {};
+  bool ready = false;
+};
+std::mutex g_gl_side_mu;
+GlSide g_gl_side[16];
+std::atomic<int> g_gl_chains{3};   // measured on 64 utterances of 200..700 frames: 1 chain 29.7, 2: 26.0, 3: 25.7, 4: 32.0 ms per 300 iterations
+
+// one wave busy for `ticks` of the 100 MHz wall clock (bounded: the loop ends when the clock has advanced)
+__global__ void gl_spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
+// Do kernels launched on a and b run side by side?  ROCm multiplexes a process's streams onto a few hardware queues (four by
+// default, least-used first), and launches of two streams that share one execute in order -- which streams share depends on
+// everything the process created before (torch's pool, the trainer's side streams).  Measured, not guessed: two 200-us spin
+// kernels take ~0.2 ms when the streams are independent and ~0.4 ms when they are not.
+bool gl_concurrent(hipStream_t a, hipStream_t b) {
+  constexpr long long TICKS = 20000;           // 200 us
+  int ok = 0;
+  for (int rep = 0; rep < 2; ++rep) {
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(gl_spin_kernel, dim3(1), dim3(64), 0, a, TICKS);
+    hipLaunchKernelGGL(gl_spin_kernel, dim3(1), dim3(64), 0, b, TICKS);
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    ok += us < 330.0;
+  }
+  return ok == 2;
+}
+
+GlSide* gl_side() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  std::lock_guard<std::mutex> lk(g_gl_side_mu);
+  GlSide& g = g_gl_side[dev];
+  if (!g.ready) {
+    g.ready = true;                            // one attempt per device and process; n stays 0 if anything fails
+    if (hipEventCreateWithFlags(&g.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    for (int i = 0; i < GL_MAX_CHAINS; ++i)
+      if (hipEventCreateWithFlags(&g.join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    hipStream_t cand[GL_CANDIDATES] = {};
+    for (int i = 0; i < GL_CANDIDATES; ++i)
+      if (hipStreamCreateWithFlags(&cand[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipDeviceSynchronize() != hipSuccess) return nullptr;      // once per process: the probe below needs a quiet device
+    bool used[GL_CANDIDATES] = {};
+    for (int i = 0; i < GL_CANDIDATES && g.n < GL_MAX_CHAINS; ++i) {
+      bool indep = true;
+      for (int k = 0; k < g.n && indep; ++k) indep = gl_concurrent(g.s[k], cand[i]);
+      if (indep) { g.s[g.n++] = cand[i]; used[i] = true; }
+    }
+    for (int i = 0; i < GL_CANDIDATES; ++i)
+      if (!used[i]) (void)hipStreamDestroy(cand[i]);
+  }
+  return g.n >= 2 ? &g : nullptr;
+}
+
+int gl_chain(const ZsGlIter& q, float* spec_a, float* spec_b, int n_iter, hipStream_t s) {
+  float* cur = spec_a;
+  float* nxt = spec_b;
+  for (int it = 0; it < n_iter; ++it) {
+    int rc = gl_launch(&q, cur, nxt, s);
+    if (rc) return rc;
+    float* t = cur; cur = nxt; nxt = t;
+  }
+  return gl_launch(&q, cur, nullptr, s);
+}
+
+}  // namespace
+
+int zs_gl_chains_option(int value) { return g_gl_chains.exchange(value < 1 ? 1 : (value > GL_MAX_CHAINS ? GL_MAX_CHAINS : value), std::memory_order_relaxed); }
+
 extern "C" int zs_griffin_lim(const ZsGlIter* p, float* spec_a, float* spec_b, int32_t n_iter, void* stream) {
   int rc = gl_check(p, "zs_griffin_lim");
   if (rc) return rc;
   ZS_REQUIRE(spec_a && spec_b && spec_a != spec_b && n_iter >= 0, "zs_griffin_lim: two distinct spectrogram buffers are required");
   ZS_REQUIRE(p->wav && p->wav_ld >= (int64_t)HOP * (p->T_max - 1), "zs_griffin_lim: wav_ld too small");
-  hipLaunchKernelGGL(gl_tables_kernel, dim3(4), dim3(256), 0, (hipStream_t)stream);
-  float* cur = spec_a;
-  float* nxt = spec_b;
-  for (int it = 0; it < n_iter; ++it) {
-    rc = gl_launch(p, cur, nxt, (hipStream_t)stream);
-    if (rc) return rc;
-    float* t = cur; cur = nxt; nxt = t;
+  hipStream_t main_s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gl_tables_kernel, dim3(4), dim3(256), 0, main_s);
+  // chains only when every one of them still has a chip's worth of frames per launch and the caller is not capturing a graph
+  int chains = g_gl_chains.load(std::memory_order_relaxed);
+  while (chains > 1 && ((int64_t)p->n_utt * p->T_max / chains < 8192 || p->n_utt < 2 * chains)) --chains;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (chains > 1 && (hipStreamIsCapturing(main_s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) chains = 1;
+  GlSide* g = chains > 1 ? gl_side() : nullptr;
+  if (g != nullptr && g->n < chains) chains = g->n;
+  if (g == nullptr || chains < 2) return gl_chain(*p, spec_a, spec_b, n_iter, main_s);
+  ZS_REQUIRE(hipEventRecord(g->fork, main_s) == hipSuccess, "zs_griffin_lim: event record");
+  const int64_t per_utt = (int64_t)p->T_max * NB;
+  // every chain gets the tile size the whole batch would get (the default depends on the launch's frame count); the launches are
+  // submitted iteration by iteration so that no chain's queue runs dry while another is being filled.
+  const int F = p->tile_frames > 0 ? p->tile_frames : ((int64_t)p->n_utt * p->T_max >= 8192 ? GL_TILE_LARGE : GL_TILE_DEFAULT);
+  ZsGlIter q[GL_MAX_CHAINS];
+  float *cur[GL_MAX_CHAINS], *nxt[GL_MAX_CHAINS];
+  hipStream_t cs[GL_MAX_CHAINS];
+  for (int c = 0; c < chains; ++c) {
+    const int u0 = (int)((int64_t)p->n_utt * c / chains), u1 = (int)((int64_t)p->n_utt * (c + 1) / chains);
+    q[c] = *p;
+    q[c].mag = p->mag + u0 * per_utt; q[c].lengths = p->lengths + u0; q[c].n_utt = u1 - u0; q[c].wav = p->wav + (int64_t)u0 * p->wav_ld;
+    q[c].tile_frames = F;
+    cur[c] = spec_a + u0 * per_utt * 2; nxt[c] = spec_b + u0 * per_utt * 2;
+    cs[c] = g->s[c];
+    ZS_REQUIRE(hipStreamWaitEvent(cs[c], g->fork, 0) == hipSuccess, "zs_griffin_lim: stream wait");
   }
-  return gl_launch(p, cur, nullptr, (hipStream_t)stream);
+  for (int it = 0; it <= n_iter; ++it)
+    for (int c = 0; c < chains; ++c) {
+      rc = gl_launch(&q[c], cur[c], it < n_iter ? nxt[c] : nullptr, cs[c]);
+      if (rc) return rc;
+      float* t = cur[c]; cur[c] = nxt[c]; nxt[c] = t;
+    }
+  for (int c = 0; c < chains; ++c)
+    ZS_REQUIRE(hipEventRecord(g->join[c], cs[c]) == hipSuccess && hipStreamWaitEvent(main_s, g->join[c], 0) == hipSuccess, "zs_griffin_lim: join");
+  return ZS_OK;
 }
 
 extern "C" int zs_gl_frame_mse(const float* wav, int64_t wav_ld, const int32_t* lengths, int32_t n_utt, int32_t frame_length, int32_t hop,
