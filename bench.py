@@ -308,10 +308,14 @@ def resynth_record(args, rank, world, dev, steps, warmup, cpu=True):
     log('resynth: Griffin-Lim per step (ms): ' + ' '.join('%.2f' % g for g in gl_ms))
     gl = sum(gl_ms) / len(gl_ms) * 1e-3
     gl_traffic = None
+    from zs_amd import _lib as ZL
+    chains = int(ZL.lib().zs_gl_chains_used())
     tpath = os.path.join(ROOT, 'profiles', GL_TRAFFIC_FILE)
     if os.path.exists(tpath) and args.utts == 64:
         kk = json.load(open(tpath)).get('kernels', {})
         gl_traffic = next((v.get('traffic_bytes_per_launch') for k, v in kk.items() if k.startswith('gl_iter_kernel')), None)
+        if gl_traffic is not None:                       # the counters are per kernel launch; an iteration is `chains` of them
+            gl_traffic *= chains
     fl = out_frames * (2 * n_iter + 1) * 2.5 * 1024 * 10          # per rank-0 shard
     by = out_frames * 513.0 * (8 + 8 + 4)                         # algorithmic bytes per launch: spectrum in + out, magnitudes in
     launch_s = gl / (n_iter + 1)
@@ -328,7 +332,7 @@ def resynth_record(args, rank, world, dev, steps, warmup, cpu=True):
                         'traffic': gl_traffic, 'traffic_unit': 'bytes/launch (committed rocprofv3 --pmc passes of this command)',
                         'kernel': 'gl_iter_kernel (one fused Griffin-Lim iteration of ALL utterances = one "launch" here; issued as up to 3 '
                                   'concurrent launches over utterance ranges on independent streams, %d iterations per batch)' % (n_iter + 1),
-                        'avg_launch_ms': 1e3 * launch_s, 'algorithmic_bytes_per_launch': by,
+                        'avg_launch_ms': 1e3 * launch_s, 'algorithmic_bytes_per_launch': by, 'concurrent_kernel_launches_per_launch': chains,
                         'fft_tflops': fl / gl / 1e12, 'fft_frac_of_fp32_vector_peak': fl / gl / 1e12 / 157.3}}
     if cpu:
         sys.path.insert(0, os.path.join(ROOT, 'oracle'))

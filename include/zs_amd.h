@@ -434,6 +434,11 @@ typedef struct {
 } ZsGlIter;
 int zs_gl_iter(const ZsGlIter* p, void* stream);
 int zs_griffin_lim(const ZsGlIter* p, float* spec_a, float* spec_b, int32_t n_iter, void* stream);
+/* zs_griffin_lim issues the loop as up to `gl_chains` (zs_set_option, default 3) independent launch chains over contiguous utterance
+ * ranges, on internal streams measured (once per process) to execute side by side, joined back into `stream` before it returns:
+ * utterances do not depend on each other, and a chain's partly filled last round of workgroups is filled by the others.  One chain
+ * for small batches (< 8192 frames per chain) and under stream capture.  zs_gl_chains_used: chains of the last call (reporting). */
+int zs_gl_chains_used(void);
 /* spectrogram2wav pre/post (convert.py:56-60): de-normalise to amplitude; de-preemphasis IIR. */
 /* ---------------------------------------------------------------------------------------------
  * Feature extraction feeding the path (preprocess.py:227-258 get_spectrograms after the host-side

@@ -448,6 +448,7 @@ struct GlSide {
 };
 std::mutex g_gl_side_mu;
 GlSide g_gl_side[16];
+std::atomic<int> g_gl_chains_used{1};
 std::atomic<int> g_gl_chains{3};   // measured on 64 utterances of 200..700 frames: 1 chain 29.7, 2: 26.0, 3: 25.7, 4: 32.0 ms per 300 iterations
 
 // one wave busy for `ticks` of the 100 MHz wall clock (bounded: the loop ends when the clock has advanced)
@@ -516,6 +517,8 @@ int gl_chain(const ZsGlIter& q, float* spec_a, float* spec_b, int n_iter, hipStr
 
 int zs_gl_chains_option(int value) { return g_gl_chains.exchange(value < 1 ? 1 : (value > GL_MAX_CHAINS ? GL_MAX_CHAINS : value), std::memory_order_relaxed); }
 
+extern "C" int zs_gl_chains_used(void) { return g_gl_chains_used.load(std::memory_order_relaxed); }
+
 extern "C" int zs_griffin_lim(const ZsGlIter* p, float* spec_a, float* spec_b, int32_t n_iter, void* stream) {
   int rc = gl_check(p, "zs_griffin_lim");
   if (rc) return rc;
@@ -530,6 +533,7 @@ extern "C" int zs_griffin_lim(const ZsGlIter* p, float* spec_a, float* spec_b, i
   if (chains > 1 && (hipStreamIsCapturing(main_s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) chains = 1;
   GlSide* g = chains > 1 ? gl_side() : nullptr;
   if (g != nullptr && g->n < chains) chains = g->n;
+  g_gl_chains_used.store(g == nullptr || chains < 2 ? 1 : chains, std::memory_order_relaxed);
   if (g == nullptr || chains < 2) return gl_chain(*p, spec_a, spec_b, n_iter, main_s);
   ZS_REQUIRE(hipEventRecord(g->fork, main_s) == hipSuccess, "zs_griffin_lim: event record");
   const int64_t per_utt = (int64_t)p->T_max * NB;
