@@ -211,6 +211,8 @@ typedef struct {
    * length are written as zeros.  res_lengths[b] <= T_res: valid rows of the ZS_RES_AVGPOOL2 residual (its odd-length
    * reflect / zero pad, model/model.py:424, happens at the sample's own end).  null = T / T_res for every sample. */
   const int32_t* lengths; const int32_t* res_lengths;
+  /* 1: mean / rstd are INPUTS (statistics computed elsewhere, e.g. by the producing kernel): the two reductions over T are skipped */
+  int32_t stats_given;
 } ZsInstNormFwd;
 int zs_instnorm_fwd(const ZsInstNormFwd* p, void* stream);
 

@@ -752,3 +752,31 @@ def test_errors_are_loud(zs):
     out = ctx.act('y', 1, 2, 8)
     with pytest.raises(L.ZsError, match='Padding size should be less'):     # same failure the reference hits for T' = 2
         l.fwd(A, out=out)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_instnorm_fwd_stats_given(zs, dtype):
+    """ZsInstNormFwd.stats_given: mean / rstd as inputs (the reductions over T skipped) -> bit for bit the output of the call that
+    computed them, with the upsampled residual and the second output of the decoder's conv blocks."""
+    L, layers = zs
+    torch.manual_seed(3)
+    B, T, C, nspk = 6, 64, 128, 3
+    ctx = _ctx(layers, dtype)
+    X = _to_act(layers, ctx, 'x', torch.randn(B, T, C) * 2 + 0.3)
+    R = _to_act(layers, ctx, 'r', torch.randn(B, T // 2, C))
+    o1, o2, p1, p2 = ctx.act('o1', B, T, C), ctx.act('o2', B, T, C), ctx.act('p1', B, T, C), ctx.act('p2', B, T, C)
+    vec2 = torch.randn(nspk, C, device=ctx.device)
+    idx = torch.tensor([0, 2, 1, 1, 0, 2], device=ctx.device)
+    mean_b, rstd_b = ctx.f32('mean', B * C), ctx.f32('rstd', B * C)
+    kw = dict(dtype=ctx.dt, x=X.ptr(), ldx=X.ld, vec2=L.ptr(vec2), vec2_ld=C, vec2_cols=C, idx=L.ptr(idx), mean=L.ptr(mean_b), rstd=L.ptr(rstd_b),
+              B=B, T=T, C=C, eps=1e-5, drop_p=0.0, res_mode=L.ZS_RES_UPSAMPLE2, res=R.ptr(), ldres=R.ld, T_res=T // 2, res_pad_mode=L.ZS_PAD_REFLECT)
+    L.call('zs_instnorm_fwd', 'ZsInstNormFwd', ctx.stream, out=o1.ptr(), ldo=o1.ld, out2=o2.ptr(), ldo2=o2.ld, **kw)
+    torch.cuda.synchronize()
+    m0, r0 = mean_b.clone(), rstd_b.clone()
+    L.call('zs_instnorm_fwd', 'ZsInstNormFwd', ctx.stream, out=p1.ptr(), ldo=p1.ld, out2=p2.ptr(), ldo2=p2.ld, stats_given=1, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(o1.valid(), p1.valid()) and torch.equal(o2.valid(), p2.valid())
+    assert torch.equal(m0, mean_b) and torch.equal(r0, rstd_b)              # inputs, not rewritten
+    with pytest.raises(L.ZsError):
+        L.call('zs_instnorm_fwd', 'ZsInstNormFwd', ctx.stream, dtype=ctx.dt, x=X.ptr(), ldx=X.ld, out=o1.ptr(), ldo=o1.ld, B=B, T=T, C=C, eps=1e-5,
+               res_mode=L.ZS_RES_NONE, stats_given=1)

@@ -1978,6 +1978,7 @@ extern "C" int zs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "gru_spin_limit")) return zs_gru_spin_limit_option(value);
   if (key && !strcmp(key, "gl_prefetch")) return zs_gl_prefetch_option(value);
   if (key && !strcmp(key, "gl_chains")) return zs_gl_chains_option(value);
+  if (key && !strcmp(key, "norm_wide")) return zs_norm_wide_option(value);
   if (!slot) { zs_set_error("zs_set_option: unknown key %s", key ? key : "(null)"); return ZS_EINVAL; }
   return slot->set(value);
 }

@@ -7,6 +7,8 @@
 // each activation is read from HBM exactly once.  These kernels are HBM-bound.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "zs_common.h"
 
 namespace {
@@ -16,23 +18,32 @@ constexpr int RPT = 8;                                   // rows per thread
 // of a row per workgroup), 32 row groups -> T <= 256.  A 512-thread / 256-channel variant (512 B of a row per workgroup)
 // measured slower in isolation (instnorm_bwd 62 vs 41 us at [256,128,1024]) and equal inside the step.
 struct Narrow { static constexpr int NTN = 256, CHUNK = 64, RG = 32; };
+// Short samples (T <= 64: the T' = 16 / 32 / 64 layers, 14 of the step's 17 norms): 8 row groups x 256 channels, so a thread still
+// has up to 8 rows in flight and a workgroup moves 4x the bytes per barrier (Narrow at T = 32: one row per thread, 1.5 TB/s).
+struct Wide8 { static constexpr int NTN = 256, CHUNK = 256, RG = 8; };
+// The reduction over T has ONE order for every decomposition: 32 partials (rows r, r + 32, ... in ascending order -- Narrow's row
+// groups), summed r = 0..31.  A thread of a decomposition with RG < 32 row groups carries NP = 32 / RG of those partials (its
+// row i belongs to partial i % NP), so a sample's statistics do not depend on the launch's T (ragged batches) nor on the variant.
+constexpr int RGN = 32;
 
-// sum the per-thread partial p[8] of channel group cg across the row groups; result broadcast.
+// sum the per-thread partials pv[NP][8] of channel group cg over the 32 canonical row groups; result broadcast into out[8].
 template <typename S>
-__device__ __forceinline__ void colreduce(float (&pv)[8], float* red, float* tot, int cg, int rg, int tid) {
-  constexpr int CHUNK = S::CHUNK, RG = S::RG;
+__device__ __forceinline__ void colreduce(const float (&pv)[RGN / S::RG][8], float (&out)[8], float* red, float* tot, int cg, int rg, int tid) {
+  constexpr int CHUNK = S::CHUNK, RG = S::RG, NP = RGN / RG;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) red[rg * CHUNK + cg * 8 + k] = pv[k];
+  for (int j = 0; j < NP; ++j)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[(rg + RG * j) * CHUNK + cg * 8 + k] = pv[j][k];
   __syncthreads();
-  if (tid < CHUNK) {
+  for (int c = tid; c < CHUNK; c += S::NTN) {
     float s = 0.f;
 #pragma unroll 8
-    for (int r = 0; r < RG; ++r) s += red[r * CHUNK + tid];
-    tot[tid] = s;
+    for (int r = 0; r < RGN; ++r) s += red[r * CHUNK + c];
+    tot[c] = s;
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < 8; ++k) pv[k] = tot[cg * 8 + k];
+  for (int k = 0; k < 8; ++k) out[k] = tot[cg * 8 + k];
   __syncthreads();
 }
 
@@ -47,8 +58,8 @@ __device__ __forceinline__ float keep_scale(const uint8_t* mask, int64_t mask_ld
 
 template <typename T, typename S>
 __global__ __launch_bounds__(S::NTN) void instnorm_fwd_kernel(const ZsInstNormFwd p) {
-  constexpr int CHUNK = S::CHUNK, RG = S::RG, CGN = S::CHUNK / 8;
-  __shared__ float red[RG * CHUNK];
+  constexpr int CHUNK = S::CHUNK, RG = S::RG, CGN = S::CHUNK / 8, NP = RGN / RG;
+  __shared__ float red[RGN * CHUNK];
   __shared__ float tot[CHUNK];
   const int tid = threadIdx.x, cg = tid % CGN, rg = tid / CGN;
   const int b = blockIdx.y, c0 = blockIdx.x * CHUNK + cg * 8;
@@ -59,7 +70,7 @@ __global__ __launch_bounds__(S::NTN) void instnorm_fwd_kernel(const ZsInstNormFw
   const int Tres_b = p.res_lengths ? p.res_lengths[b] : p.T_res;
   const T* x = (const T*)p.x;
   Raw8<T> v[RPT];            // rows stay as loaded (bf16: 4 registers per 8 values instead of 8) between the passes: occupancy
-  float s[8];
+  float s[NP][8];
   // the residual rows are fetched together with x (raw: they are not needed before the second pass), so that their HBM
   // latency is not paid again behind the two reductions
   const T* res = (const T*)p.res;
@@ -78,39 +89,53 @@ __global__ __launch_bounds__(S::NTN) void instnorm_fwd_kernel(const ZsInstNormFw
     }
   }
 #pragma unroll
-  for (int k = 0; k < 8; ++k) s[k] = 0.f;
+  for (int j = 0; j < NP; ++j)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[j][k] = 0.f;
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
     const int t = rg + RG * i;
     v[i].zero();
     if (cvalid && t < Tb) v[i].ld(x + ((int64_t)b * p.T + t) * p.ldx + c0);
   }
-#pragma unroll
-  for (int i = 0; i < RPT; ++i) {
-    float f[8]; v[i].cvt(f);                      // rows past T are zeros
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s[k] += f[k];
-  }
-  colreduce<S>(s, red, tot, cg, rg, tid);
-  float mean[8], q[8];
+  float mean[8], rstd[8];
   const float invT = 1.f / (float)Tb;
+  if (p.stats_given) {                                                         // (kernel-uniform) statistics from the caller
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { mean[k] = s[k] * invT; q[k] = 0.f; }
-#pragma unroll
-  for (int i = 0; i < RPT; ++i) {
-    const int t = rg + RG * i;
-    if (t < Tb) {
-      float f[8]; v[i].cvt(f);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { const float d = f[k] - mean[k]; q[k] += d * d; }
+    for (int k = 0; k < 8; ++k) {
+      mean[k] = cvalid ? p.mean[(int64_t)b * p.C + c0 + k] : 0.f;
+      rstd[k] = cvalid ? p.rstd[(int64_t)b * p.C + c0 + k] : 0.f;
     }
-  }
-  colreduce<S>(q, red, tot, cg, rg, tid);
-  float rstd[8];
+  } else {
 #pragma unroll
-  for (int k = 0; k < 8; ++k) rstd[k] = 1.f / sqrtf(q[k] * invT + p.eps);
+    for (int i = 0; i < RPT; ++i) {
+      float f[8]; v[i].cvt(f);                    // rows past T are zeros
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[i % NP][k] += f[k];
+    }
+    float tsum[8];
+    colreduce<S>(s, tsum, red, tot, cg, rg, tid);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) mean[k] = tsum[k] * invT;
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[j][k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int t = rg + RG * i;
+      if (t < Tb) {
+        float f[8]; v[i].cvt(f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float d = f[k] - mean[k]; s[i % NP][k] += d * d; }
+      }
+    }
+    colreduce<S>(s, tsum, red, tot, cg, rg, tid);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rstd[k] = 1.f / sqrtf(tsum[k] * invT + p.eps);
+  }
   if (!cvalid) return;
-  if (p.mean && rg == 0) {
+  if (p.mean && rg == 0 && !p.stats_given) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) { p.mean[(int64_t)b * p.C + c0 + k] = mean[k]; p.rstd[(int64_t)b * p.C + c0 + k] = rstd[k]; }
   }
@@ -168,8 +193,8 @@ __global__ __launch_bounds__(S::NTN) void instnorm_fwd_kernel(const ZsInstNormFw
 
 template <typename T, typename S>
 __global__ __launch_bounds__(S::NTN) void instnorm_bwd_kernel(const ZsInstNormBwd p) {
-  constexpr int CHUNK = S::CHUNK, RG = S::RG, CGN = S::CHUNK / 8;
-  __shared__ float red[RG * CHUNK];
+  constexpr int CHUNK = S::CHUNK, RG = S::RG, CGN = S::CHUNK / 8, NP = RGN / RG;
+  __shared__ float red[RGN * CHUNK];
   __shared__ float tot[CHUNK];
   const int tid = threadIdx.x, cg = tid % CGN, rg = tid / CGN;
   const int b = blockIdx.y, c0 = blockIdx.x * CHUNK + cg * 8;
@@ -183,9 +208,11 @@ __global__ __launch_bounds__(S::NTN) void instnorm_bwd_kernel(const ZsInstNormBw
   const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
   const uint64_t seed = p.seed + (p.seed_ptr ? *p.seed_ptr : 0ull);
   Raw8<T> g[RPT], xv[RPT];      // as loaded: 8 instead of 16 registers per row pair in bf16 (this kernel was at 256 VGPRs)
-  float sg[8], sgx[8];
+  float pg[NP][8], pgx[NP][8], sg[8], sgx[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { sg[k] = 0.f; sgx[k] = 0.f; }
+  for (int j = 0; j < NP; ++j)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { pg[j][k] = 0.f; pgx[j][k] = 0.f; }
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
     const int t = rg + RG * i;
@@ -207,12 +234,12 @@ __global__ __launch_bounds__(S::NTN) void instnorm_bwd_kernel(const ZsInstNormBw
       for (int k = 0; k < 8; ++k) {
         gf[k] *= keep_scale(p.mask, p.mask_ld, p.drop_p, seed, p.stream_id, row, c0 + k, p.C, inv_keep);
         const float xh = (xf[k] - mean[k]) * rstd[k];
-        sg[k] += gf[k]; sgx[k] += gf[k] * xh;
+        pg[i % NP][k] += gf[k]; pgx[i % NP][k] += gf[k] * xh;
       }
     }
   }
-  colreduce<S>(sg, red, tot, cg, rg, tid);
-  colreduce<S>(sgx, red, tot, cg, rg, tid);
+  colreduce<S>(pg, sg, red, tot, cg, rg, tid);
+  colreduce<S>(pgx, sgx, red, tot, cg, rg, tid);
   if (!cvalid) return;
   const float invT = 1.f / (float)p.T;
 #pragma unroll
@@ -235,8 +262,8 @@ __global__ __launch_bounds__(S::NTN) void instnorm_bwd_kernel(const ZsInstNormBw
 
 template <typename T, typename S>
 __global__ __launch_bounds__(S::NTN) void grad_combine_kernel(const ZsGradCombine p) {
-  constexpr int CHUNK = S::CHUNK, RG = S::RG, CGN = S::CHUNK / 8;
-  __shared__ float red[RG * CHUNK];
+  constexpr int CHUNK = S::CHUNK, RG = S::RG, CGN = S::CHUNK / 8, NP = RGN / RG;
+  __shared__ float red[RGN * CHUNK];
   __shared__ float tot[CHUNK];
   const int tid = threadIdx.x, cg = tid % CGN, rg = tid / CGN;
   const int b = blockIdx.y, c0 = blockIdx.x * CHUNK + cg * 8;
@@ -244,9 +271,11 @@ __global__ __launch_bounds__(S::NTN) void grad_combine_kernel(const ZsGradCombin
   const int Tp = p.T + p.pad_left + p.pad_right;
   const T* gp = (const T*)p.gp;
   float v[RPT][8];
-  float s[8];
+  float ps[NP][8], s[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) s[k] = 0.f;
+  for (int j = 0; j < NP; ++j)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ps[j][k] = 0.f;
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
     const int t = rg + RG * i;
@@ -268,11 +297,11 @@ __global__ __launch_bounds__(S::NTN) void grad_combine_kernel(const ZsGradCombin
         }
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) s[k] += v[i][k];
+      for (int k = 0; k < 8; ++k) ps[i % NP][k] += v[i][k];
     }
   }
   if (p.emb_sum) {                                             // uniform branch
-    colreduce<S>(s, red, tot, cg, rg, tid);
+    colreduce<S>(ps, s, red, tot, cg, rg, tid);
     if (cvalid && rg == 0) {                                   // this workgroup owns (b, these channels): plain RMW
 #pragma unroll
       for (int k = 0; k < 8; ++k)
@@ -317,10 +346,34 @@ __global__ __launch_bounds__(S::NTN) void grad_combine_kernel(const ZsGradCombin
 
 bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+std::atomic<int> g_norm_wide{1};
+// Wide8 for short samples of wide layers in bf16 (fp32 rows are twice the registers; it is the parity dtype, not the fast one)
+// Measured at B = 256, C = 1024 (tools/instnorm_probe.py), 32x64 -> 8x256: forward T = 16 / 32 / 64: 29.3 -> 12.0, 31.3 -> 16.8,
+// 36.6 -> 26.4 us; backward 18.5 -> 14.8, 19.6 -> 19.1, 25.3 -> 30.3 us: the forward takes it up to T = 64, the others up to 16.
+bool norm_wide(int dtype, int T, int C, int max_T) {
+  return g_norm_wide.load(std::memory_order_relaxed) != 0 && dtype == ZS_BF16 && T <= max_T && T <= Wide8::RG * RPT && C >= Wide8::CHUNK;
+}
+
+#define ZS_NORM_LAUNCH(KERNEL, MAXT)                                                                                            \
+  do {                                                                                                                      \
+    if (norm_wide(p->dtype, p->T, p->C, MAXT)) {                                                                           \
+      dim3 grid((p->C + Wide8::CHUNK - 1) / Wide8::CHUNK, p->B);                                                            \
+      hipLaunchKernelGGL((KERNEL<bf16_t, Wide8>), grid, dim3(Wide8::NTN), 0, (hipStream_t)stream, *p);                      \
+    } else {                                                                                                                \
+      dim3 grid((p->C + Narrow::CHUNK - 1) / Narrow::CHUNK, p->B);                                                          \
+      if (p->dtype == ZS_F32) hipLaunchKernelGGL((KERNEL<float, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p); \
+      else hipLaunchKernelGGL((KERNEL<bf16_t, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);                \
+    }                                                                                                                       \
+  } while (0)
+
 }  // namespace
+
+// "norm_wide" knob of zs_set_option
+int zs_norm_wide_option(int value) { return g_norm_wide.exchange(value ? 1 : 0, std::memory_order_relaxed); }
 
 extern "C" int zs_instnorm_fwd(const ZsInstNormFwd* p, void* stream) {
   ZS_REQUIRE(p && p->x && p->out, "zs_instnorm_fwd: null operand");
+  ZS_REQUIRE(!p->stats_given || (p->mean && p->rstd), "zs_instnorm_fwd: stats_given needs mean and rstd");
   ZS_REQUIRE(p->dtype == ZS_F32 || p->dtype == ZS_BF16, "zs_instnorm_fwd: bad dtype");
   const int es = p->dtype == ZS_F32 ? 4 : 2;
   ZS_REQUIRE(p->B > 0 && p->T > 0 && p->T <= Narrow::RG * RPT && p->C > 0 && p->C % 8 == 0, "zs_instnorm_fwd: need 0<T<=256 (T=%d), C%%8==0 (C=%d)", p->T, p->C);
@@ -333,9 +386,7 @@ extern "C" int zs_instnorm_fwd(const ZsInstNormFwd* p, void* stream) {
     if (p->res_mode == ZS_RES_AVGPOOL2) ZS_REQUIRE((p->T_res + 1) / 2 == p->T && p->T_res >= 2, "zs_instnorm_fwd: avgpool T_res %d vs T %d", p->T_res, p->T);
   }
   ZS_REQUIRE(p->drop_p >= 0.f && p->drop_p < 1.f, "zs_instnorm_fwd: drop_p");
-  dim3 grid((p->C + Narrow::CHUNK - 1) / Narrow::CHUNK, p->B);
-  if (p->dtype == ZS_F32) hipLaunchKernelGGL((instnorm_fwd_kernel<float, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);
-  else hipLaunchKernelGGL((instnorm_fwd_kernel<bf16_t, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);
+  ZS_NORM_LAUNCH(instnorm_fwd_kernel, 64);
   return zs_check_launch("zs_instnorm_fwd");
 }
 
@@ -346,9 +397,7 @@ extern "C" int zs_instnorm_bwd(const ZsInstNormBwd* p, void* stream) {
   ZS_REQUIRE(p->B > 0 && p->T > 0 && p->T <= Narrow::RG * RPT && p->C > 0 && p->C % 8 == 0, "zs_instnorm_bwd: sizes");
   ZS_REQUIRE(al16(p->dout) && al16(p->x) && al16(p->dz) && (p->ldd * es) % 16 == 0 && (p->ldx * es) % 16 == 0 && (p->ldz * es) % 16 == 0,
              "zs_instnorm_bwd: alignment");
-  dim3 grid((p->C + Narrow::CHUNK - 1) / Narrow::CHUNK, p->B);
-  if (p->dtype == ZS_F32) hipLaunchKernelGGL((instnorm_bwd_kernel<float, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);
-  else hipLaunchKernelGGL((instnorm_bwd_kernel<bf16_t, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);
+  ZS_NORM_LAUNCH(instnorm_bwd_kernel, 16);
   return zs_check_launch("zs_instnorm_bwd");
 }
 
@@ -366,8 +415,6 @@ extern "C" int zs_grad_combine(const ZsGradCombine* p, void* stream) {
   }
   ZS_REQUIRE(!p->unshuffle || (p->T % 2 == 0 && (p->C * es) % 16 == 0), "zs_grad_combine: unshuffle");
   ZS_REQUIRE(!p->dact_src || (al16(p->dact_src) && (p->dact_ld * es) % 16 == 0), "zs_grad_combine: dact");
-  dim3 grid((p->C + Narrow::CHUNK - 1) / Narrow::CHUNK, p->B);
-  if (p->dtype == ZS_F32) hipLaunchKernelGGL((grad_combine_kernel<float, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);
-  else hipLaunchKernelGGL((grad_combine_kernel<bf16_t, Narrow>), grid, dim3(Narrow::NTN), 0, (hipStream_t)stream, *p);
+  ZS_NORM_LAUNCH(grad_combine_kernel, 16);
   return zs_check_launch("zs_grad_combine");
 }
