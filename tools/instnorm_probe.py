@@ -52,20 +52,34 @@ for T in (32, 64, 128):
     tot[0] += a; tot[1] += b
 print('three decoder conv blocks per step: %.1f us -> %.1f us with the statistics given (-%.1f us of a 10.9 ms step)' % (tot[0], tot[1], tot[0] - tot[1]))
 
-# the decomposition for short samples (zs_set_option 'norm_wide'): 8 row groups x 256 channels against 32 x 64, T' = 16 layers included
-for T in (16, 32, 64):
+# the decompositions (workgroup = row groups x channels): 32x64 (Narrow) and 8x256 (T <= 64) for the three kernels that share them.
+# grad_combine as the decoder's conv blocks call it: reflect-pad fold of a k = 3 data gradient, un-pixel-shuffle, lrelu'.
+def shapes(T):
+    out = [('32x64', dict(norm_wide=0))]
+    if T <= 64:
+        out.append(('8x256', dict(norm_wide=1, norm_lim0=64, norm_lim1=64, norm_lim2=64)))
+    return out
+
+
+for T in (16, 32, 64, 128):
     X, R = ctx.act('wx%d' % T, B, T, C), ctx.act('wr%d' % T, B, T, C)
     X.valid().copy_(torch.randn(B, T, C, device=dev)); R.valid().copy_(torch.randn(B, T, C, device=dev))
     o1, dz = ctx.act('wo%d' % T, B, T, C), ctx.act('wdz%d' % T, B, T, C)
+    gp, da, oc = ctx.act('wgp%d' % T, B, T + 2, C), ctx.act('wda%d' % T, B, T // 2, 2 * C), ctx.act('woc%d' % T, B, T // 2, 2 * C)
+    gp.valid().copy_(torch.randn(B, T + 2, C, device=dev)); da.valid().copy_(torch.randn(B, T // 2, 2 * C, device=dev))
     mean_b, rstd_b = ctx.f32('wmean%d' % T, B * C), ctx.f32('wrstd%d' % T, B * C)
     fw = dict(dtype=ctx.dt, x=X.ptr(), ldx=X.ld, out=o1.ptr(), ldo=o1.ld, mean=L.ptr(mean_b), rstd=L.ptr(rstd_b), B=B, T=T, C=C, eps=1e-5,
               drop_p=0.0, res_mode=L.ZS_RES_IDENTITY, res=R.ptr(), ldres=R.ld, T_res=T, res_pad_mode=L.ZS_PAD_REFLECT)
     bw = dict(dtype=ctx.dt, dout=R.ptr(), ldd=R.ld, x=X.ptr(), ldx=X.ld, mean=L.ptr(mean_b), rstd=L.ptr(rstd_b), dz=dz.ptr(), ldz=dz.ld,
               B=B, T=T, C=C, drop_p=0.0, slope=0.01)
-    res = {}
-    for wide in (0, 1):
-        L.set_option('norm_wide', wide)
-        res[wide] = (timeit(lambda: L.call('zs_instnorm_fwd', 'ZsInstNormFwd', ctx.stream, **fw)),
-                     timeit(lambda: L.call('zs_instnorm_bwd', 'ZsInstNormBwd', ctx.stream, **bw)))
-    print('B=%d T=%3d C=%d  instnorm_fwd 32x64: %.1f us, 8x256: %.1f us;  instnorm_bwd 32x64: %.1f us, 8x256: %.1f us' %
-          (B, T, C, res[0][0], res[1][0], res[0][1], res[1][1]), flush=True)
+    gc = dict(dtype=ctx.dt, gp=gp.ptr(), ldg=gp.ld, pad_left=1, pad_right=1, pad_mode=L.ZS_PAD_REFLECT, B=B, T=T, C=C, res_mode=L.ZS_RES_NONE,
+              dact_src=da.ptr(), dact_ld=da.ld, slope=0.01, out=oc.ptr(), ldo=oc.ld, unshuffle=1)
+    line = 'B=%d T=%3d C=%d ' % (B, T, C)
+    for name, opts in shapes(T):
+        for k, v in opts.items():
+            L.set_option(k, v)
+        line += ' | %s: fwd %.1f bwd %.1f combine %.1f us' % (
+            name, timeit(lambda: L.call('zs_instnorm_fwd', 'ZsInstNormFwd', ctx.stream, **fw)),
+            timeit(lambda: L.call('zs_instnorm_bwd', 'ZsInstNormBwd', ctx.stream, **bw)),
+            timeit(lambda: L.call('zs_grad_combine', 'ZsGradCombine', ctx.stream, **gc)))
+    print(line, flush=True)

@@ -16,6 +16,7 @@ void zs_set_error(const char* fmt, ...);
 int zs_check_launch(const char* what);
 int zs_gl_prefetch_option(int value);    // zs_griffin.hip: "gl_prefetch" knob
 int zs_norm_wide_option(int value);      // zs_norm.hip: "norm_wide" knob (8 row groups x 256 channels for T <= 64)
+int zs_norm_lim_option(int i, int value);
 int zs_gl_chains_option(int value);      // zs_griffin.hip: "gl_chains" knob (independent launch chains of zs_griffin_lim)
 int zs_gru_spin_limit_option(int value); // zs_gru.hip: "gru_spin_limit" knob, returns the previous value
 int zs_gru_persist_option(int value);   // zs_gru.hip: "gru_persist" knob, returns the previous value

@@ -1979,6 +1979,7 @@ extern "C" int zs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "gl_prefetch")) return zs_gl_prefetch_option(value);
   if (key && !strcmp(key, "gl_chains")) return zs_gl_chains_option(value);
   if (key && !strcmp(key, "norm_wide")) return zs_norm_wide_option(value);
+  if (key && !strncmp(key, "norm_lim", 8) && key[8] >= '0' && key[8] <= '2' && !key[9]) return zs_norm_lim_option(key[8] - '0', value);
   if (!slot) { zs_set_error("zs_set_option: unknown key %s", key ? key : "(null)"); return ZS_EINVAL; }
   return slot->set(value);
 }

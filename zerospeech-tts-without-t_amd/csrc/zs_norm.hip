@@ -347,16 +347,23 @@ __global__ __launch_bounds__(S::NTN) void grad_combine_kernel(const ZsGradCombin
 bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 std::atomic<int> g_norm_wide{1};
+// longest T that takes the 8x256 decomposition in instnorm_fwd, instnorm_bwd, grad_combine ("norm_lim0..2" knobs: tools/instnorm_probe.py)
+int g_norm_lim[3] = {64, 32, 64};
 // Wide8 for short samples of wide layers in bf16 (fp32 rows are twice the registers; it is the parity dtype, not the fast one)
-// Measured at B = 256, C = 1024 (tools/instnorm_probe.py), 32x64 -> 8x256: forward T = 16 / 32 / 64: 29.3 -> 12.0, 31.3 -> 16.8,
-// 36.6 -> 26.4 us; backward 18.5 -> 14.8, 19.6 -> 19.1, 25.3 -> 30.3 us: the forward takes it up to T = 64, the others up to 16.
+// Measured at B = 256, C = 1024, bf16 (tools/instnorm_probe.py; us for 32x64 | 8x256):
+//   forward   T = 16: 29.2 | 11.9   32: 31.4 | 17.0   64: 36.6 | 26.2
+//   backward  T = 16: 18.4 | 14.7   32: 19.7 | 19.1   64: 25.4 | 30.7
+//   combine   T = 16:  7.7 |  7.0   32: 11.6 |  9.1   64: 18.0 | 16.0
+// A 16x128 decomposition for T <= 128 won 10 % on the forward kernel alone (50.1 -> 44.9 us) and nothing in the step
+// (11.05-11.07 against 11.01-11.03 ms with 8x256 only, same box): not kept.
+// 8x256 for short samples of wide layers in bf16 (fp32 rows are twice the registers; it is the parity dtype, not the fast one)
 bool norm_wide(int dtype, int T, int C, int max_T) {
   return g_norm_wide.load(std::memory_order_relaxed) != 0 && dtype == ZS_BF16 && T <= max_T && T <= Wide8::RG * RPT && C >= Wide8::CHUNK;
 }
 
-#define ZS_NORM_LAUNCH(KERNEL, MAXT)                                                                                            \
+#define ZS_NORM_LAUNCH(KERNEL, MAXT)                                                                                        \
   do {                                                                                                                      \
-    if (norm_wide(p->dtype, p->T, p->C, MAXT)) {                                                                           \
+    if (norm_wide(p->dtype, p->T, p->C, MAXT)) {                                                                            \
       dim3 grid((p->C + Wide8::CHUNK - 1) / Wide8::CHUNK, p->B);                                                            \
       hipLaunchKernelGGL((KERNEL<bf16_t, Wide8>), grid, dim3(Wide8::NTN), 0, (hipStream_t)stream, *p);                      \
     } else {                                                                                                                \
@@ -368,6 +375,7 @@ bool norm_wide(int dtype, int T, int C, int max_T) {
 
 }  // namespace
 
+int zs_norm_lim_option(int i, int value) { const int o = g_norm_lim[i]; g_norm_lim[i] = value; return o; }
 // "norm_wide" knob of zs_set_option
 int zs_norm_wide_option(int value) { return g_norm_wide.exchange(value ? 1 : 0, std::memory_order_relaxed); }
 
@@ -386,7 +394,7 @@ extern "C" int zs_instnorm_fwd(const ZsInstNormFwd* p, void* stream) {
     if (p->res_mode == ZS_RES_AVGPOOL2) ZS_REQUIRE((p->T_res + 1) / 2 == p->T && p->T_res >= 2, "zs_instnorm_fwd: avgpool T_res %d vs T %d", p->T_res, p->T);
   }
   ZS_REQUIRE(p->drop_p >= 0.f && p->drop_p < 1.f, "zs_instnorm_fwd: drop_p");
-  ZS_NORM_LAUNCH(instnorm_fwd_kernel, 64);
+  ZS_NORM_LAUNCH(instnorm_fwd_kernel, g_norm_lim[0]);
   return zs_check_launch("zs_instnorm_fwd");
 }
 
@@ -397,7 +405,7 @@ extern "C" int zs_instnorm_bwd(const ZsInstNormBwd* p, void* stream) {
   ZS_REQUIRE(p->B > 0 && p->T > 0 && p->T <= Narrow::RG * RPT && p->C > 0 && p->C % 8 == 0, "zs_instnorm_bwd: sizes");
   ZS_REQUIRE(al16(p->dout) && al16(p->x) && al16(p->dz) && (p->ldd * es) % 16 == 0 && (p->ldx * es) % 16 == 0 && (p->ldz * es) % 16 == 0,
              "zs_instnorm_bwd: alignment");
-  ZS_NORM_LAUNCH(instnorm_bwd_kernel, 16);
+  ZS_NORM_LAUNCH(instnorm_bwd_kernel, g_norm_lim[1]);
   return zs_check_launch("zs_instnorm_bwd");
 }
 
@@ -415,6 +423,6 @@ extern "C" int zs_grad_combine(const ZsGradCombine* p, void* stream) {
   }
   ZS_REQUIRE(!p->unshuffle || (p->T % 2 == 0 && (p->C * es) % 16 == 0), "zs_grad_combine: unshuffle");
   ZS_REQUIRE(!p->dact_src || (al16(p->dact_src) && (p->dact_ld * es) % 16 == 0), "zs_grad_combine: dact");
-  ZS_NORM_LAUNCH(grad_combine_kernel, 16);
+  ZS_NORM_LAUNCH(grad_combine_kernel, g_norm_lim[2]);
   return zs_check_launch("zs_grad_combine");
 }
