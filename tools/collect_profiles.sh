@@ -29,7 +29,7 @@ python3 tools/resynth_trace.py $(find $O/resynth -name "*kernel_trace.csv" | hea
 python3 tools/pmc_traffic.py $(find $O/resynth_f -name "*counter_collection.csv" | head -1) $(find $O/resynth_w -name "*counter_collection.csv" | head -1) $P/r03_resynth_pmc_traffic.json > $P/r03_resynth_pmc_traffic.txt
 cp $(find $O/dstep -name "*kernel_stats.csv" | head -1) $P/r03_stage2_dstep_kernel_stats.csv
 python3 tools/kernel_stats_per.py $P/r03_stage2_dstep_kernel_stats.csv 7 30 > $P/r03_stage2_dstep_per_step.txt
-tail -1 $O/dstep.txt >> $P/r03_stage2_dstep_per_step.txt
+grep "D step" $O/dstep.txt | tail -1 >> $P/r03_stage2_dstep_per_step.txt
 cp $O/train.json $P/r03_bench_train_under_rocprof.json
 cp $O/resynth.json $P/r03_bench_resynth_under_rocprof.json
 rm -rf $O
