@@ -104,6 +104,12 @@ typedef struct {
    * rows past a sample's length are computed from zero rows (finite, never read by a length-aware consumer).  T_in / T_out stay
    * the row strides of the batch.  gather 0 only; B < 65536, T_in < 32768.  null = every sample has T_in rows. */
   const int32_t* lengths; int32_t pad_right;
+  /* 2-D convolution (w_in > 0; nn.Conv2d of the stage-2 critic, model/model.py:113-173, on channels-last [B, H*W, C] rows): a
+   * sample's T_in rows are an (T_in / w_in) x w_in image, its T_out output rows an (T_out / w_out) x w_out image, tap
+   * j = kw*taps_h + kh (kw = j / taps_h along the row, kh = j % taps_h across rows: the order of nn.Conv2d's weight [co][ci][kw][kh]
+   * when W is the frequency axis); the gather rule above applies per axis with the same stride, pad_left and pad_mode.
+   * 0 = the 1-D convolution over T.  Not with lengths. */
+  int32_t w_in, w_out, taps_h;
 } ZsGemmConv;
 int zs_gemm_conv(const ZsGemmConv* p, void* stream);
 
@@ -130,6 +136,7 @@ typedef struct {
   int32_t co_split2; int32_t accumulate;
   int32_t splits;                  /* 0 = choose */
   void* workspace; size_t workspace_bytes;
+  int32_t w_in, w_out, taps_h;     /* 2-D convolution: as in ZsGemmConv (dW[co, ci, j], j = kw*taps_h + kh); 0 = 1-D */
 } ZsGemmWgrad;
 size_t zs_gemm_wgrad_workspace_bytes(const ZsGemmWgrad* p);
 int zs_gemm_wgrad(const ZsGemmWgrad* p, void* stream);
@@ -506,6 +513,20 @@ typedef struct {
   int32_t full;                                   /* transpose of zs_conv2d_gather(full): gp rows (b, ho, wo), columns (kh*k + kw)*C + c */
 } ZsConv2dFold;
 int zs_conv2d_fold(const ZsConv2dFold* p, void* stream);
+/* zs_conv2d_unpad: the last step of a stride-2 Conv2d's data gradient computed by output parity (ZsGemmConv with w_in > 0,
+ * gather 1): class (ph, pw) holds the gradient at the positions (2 h2 + ph, 2 w2 + pw) of the PADDED input domain
+ * [Hp][Wp] as rows [B][Hc(ph) * Wc(pw)], Hc(ph) = (Hp - ph + 1) / 2, Wc(pw) = (Wp - pw + 1) / 2.  This kernel removes the
+ * padding -- reflect pads fold back onto the interior positions they mirrored (model/model.py pad_layer_2d), zero pads are
+ * dropped -- and interleaves the classes:
+ *   out[b][h*W + w][c] = sum over (h', w') in {(h, w) and its reflection partners} of g<(h'+pad)&1><(w'+pad)&1>[...] (+ add) */
+typedef struct {
+  int32_t dtype;
+  const void* g00; const void* g01; const void* g10; const void* g11; int64_t ldg;      /* g<ph><pw> */
+  int32_t B, H, W, C, Hp, Wp, pad, pad_mode;
+  const void* add; int64_t ldadd;                 /* optional rows added (T dtype, same shape as out) */
+  void* out; int64_t ldo; int32_t fill_cols;      /* [B][H*W] rows, zero filled to fill_cols */
+} ZsConv2dUnpad;
+int zs_conv2d_unpad(const ZsConv2dUnpad* p, void* stream);
 
 /* zs_row_moments: per (b, c) sums over the T rows of a sample, two-stage in a fixed order (no atomics):
  *   u' = u - center_sum[b][c]*center_scale (if center_sum);  m = y ? lrelu'(y) : 1

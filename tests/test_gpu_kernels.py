@@ -780,3 +780,58 @@ def test_instnorm_fwd_stats_given(zs, dtype):
     with pytest.raises(L.ZsError):
         L.call('zs_instnorm_fwd', 'ZsInstNormFwd', ctx.stream, dtype=ctx.dt, x=X.ptr(), ldx=X.ld, out=o1.ptr(), ldo=o1.ld, B=B, T=T, C=C, eps=1e-5,
                res_mode=L.ZS_RES_NONE, stats_given=1)
+
+
+CONV2D_CASES = [
+    # B, H, W, Cin, Cout, k, reflect
+    (2, 12, 17, 16, 24, 5, True), (3, 16, 33, 64, 128, 5, True), (2, 8, 17, 128, 96, 5, True), (2, 12, 17, 32, 40, 5, False),
+    (2, 9, 10, 64, 64, 3, True), (1, 64, 65, 64, 128, 5, True),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', CONV2D_CASES)
+def test_conv2d_layer_vs_torch(zs, dtype, case, gemm_variant):
+    """layers.Conv2dLayer (2-D taps in the GEMM kernels' row pointers: ZsGemmConv.w_in / ZsGemmWgrad.w_in, stride-2 data gradient by
+    (h, w) output parity + zs_conv2d_unpad) against torch: nn.Conv2d on the reflect- / zero-padded input, stride 2, its autograd
+    data, weight and bias gradients.  Rows layout [B, H*W, C]; the weight's kernel dims run along (W, H)."""
+    L, layers = zs
+    B, H, W, Cin, Cout, k, reflect = case
+    g = torch.Generator().manual_seed(5)
+    x = _round(torch.randn(B, H, W, Cin, generator=g), dtype).requires_grad_(True)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)        # [co, ci, kw, kh]
+    wr = _round(w, dtype).requires_grad_(True)
+    b = torch.randn(Cout, generator=g).requires_grad_(True)
+    p = k // 2
+    xp = F.pad(x.permute(0, 3, 2, 1), (p, p, p, p), mode='reflect' if reflect else 'constant')       # [B, C, W, H]: dims (2, 3) = (kw, kh)
+    y = F.conv2d(xp, wr, b, stride=2).permute(0, 3, 2, 1)                                               # [B, Ho, Wo, Cout]
+    dy = _round(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+    ctx = _ctx(layers, dtype)
+    dev = ctx.device
+    w_d, b_d = w.to(dev).contiguous(), b.detach().to(dev).contiguous()
+    lay = layers.Conv2dLayer(ctx, w_d, b_d, torch.zeros_like(w_d), torch.zeros_like(b_d), stride=2,
+                             pad_mode=(L.ZS_PAD_REFLECT if reflect else L.ZS_PAD_ZERO), name='t2d')
+    lay.pack()
+    Ho, Wo = lay.out_hw(H, W)
+    assert (Ho, Wo) == (y.shape[1], y.shape[2])
+    X = _to_act(layers, ctx, 'x2', x.detach().reshape(B, H * W, Cin))
+    out = ctx.act('y2', B, Ho * Wo, Cout)
+    lay.fwd(X, H, W, out)
+    dY = _to_act(layers, ctx, 'dy2', dy.reshape(B, Ho * Wo, Cout))
+    dx = ctx.act('dx2', B, H * W, Cin)
+    lay.dgrad(dY, H, W, dx, 't2d_g')
+    lay.wgrad(dY, X, H, W)
+    torch.cuda.synchronize()
+    tol = _tol(dtype)
+    _close('conv2d fwd', out.valid(), y.detach().reshape(B, Ho * Wo, Cout), tol)
+    _close('conv2d dx', dx.valid(), x.grad.reshape(B, H * W, Cin), tol)
+    _close('conv2d dW', lay.gw, wr.grad, tol)
+    _close('conv2d db', lay.gb, b.grad, tol)
+    # accumulate + add operand
+    add = _to_act(layers, ctx, 'add2', torch.ones(B, H * W, Cin))
+    lay.dgrad(dY, H, W, dx, 't2d_g', add=add)
+    lay.wgrad(dY, X, H, W, accumulate=True)
+    torch.cuda.synchronize()
+    _close('conv2d dx + add', dx.valid(), x.grad.reshape(B, H * W, Cin) + 1.0, tol)
+    _close('conv2d dW accumulated', lay.gw, 2 * wr.grad, tol)

@@ -58,6 +58,20 @@ __device__ __forceinline__ int conv_src_row(int gather, int pad_mode, int stride
   return q;
 }
 
+// 2-D convolutions (ZsGemmConv.w_in > 0): a sample's rows are an H x w_in image, output position t = (t / w_out, t % w_out), tap
+// j = (kw, kh) = (j / taps_h, j % taps_h) -- the 1-D rule applied per axis (same stride, padding and pad mode on both).
+__device__ __forceinline__ int conv_src_row_g(int gather, int pad_mode, int stride, int pad_left, int T_in, int t, int j, bool& ok,
+                                              int w_in, int w_out, int taps_h) {
+  if (w_in == 0) return conv_src_row(gather, pad_mode, stride, pad_left, T_in, t, j, ok);
+  const int ho = t / w_out, wo = t - ho * w_out;
+  const int kw = j / taps_h, kh = j - kw * taps_h;
+  bool ok_h, ok_w;
+  const int h = conv_src_row(gather, pad_mode, stride, pad_left, T_in / w_in, ho, kh, ok_h);
+  const int w = conv_src_row(gather, pad_mode, stride, pad_left, w_in, wo, kw, ok_w);
+  ok = ok_h && ok_w;
+  return h * w_in + w;
+}
+
 // (sample, position) of output row m for the A-row loaders.  rb < 0: the row contributes zeros (beyond M, or beyond its sample's
 // length in a ragged batch).  With p.lengths the sample's own input length rides in the upper half of rb (see conv_row_*).
 __device__ __forceinline__ void conv_row_setup(const ZsGemmConv& p, int m, int M, int& rb, int& rt) {
@@ -346,7 +360,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_conv_kernel(const ZsGemmConv p) {
 #define ZS_SET_TAP(i, ptr, inc)                                                                         \
   {                                                                                                     \
     bool ok = false; int srow = 0;                                                                      \
-    if (rb[i] >= 0) srow = conv_src_row(p.gather, p.pad_mode, p.stride, p.pad_left, conv_row_tin(p, rb[i]), rt[i], tap, ok); \
+    if (rb[i] >= 0) srow = conv_src_row_g(p.gather, p.pad_mode, p.stride, p.pad_left, conv_row_tin(p, rb[i]), rt[i], tap, ok, p.w_in, p.w_out, p.taps_h); \
     ptr = ok ? (A + (int64_t)conv_row_b(p, rb[i]) * p.a_batch_stride + (int64_t)srow * p.lda + seg * EPS) : zline;       \
     inc = ok ? KC : 0;                                                                                  \
   }
@@ -486,7 +500,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_conv_dma_kernel(const ZsGemmConv p
 #define ZS_SET_TAP(i, ptr, inc)                                                                         \
   {                                                                                                     \
     bool ok = false; int srow = 0;                                                                      \
-    if (rb[i] >= 0) srow = conv_src_row(p.gather, p.pad_mode, p.stride, p.pad_left, conv_row_tin(p, rb[i]), rt[i], tap, ok); \
+    if (rb[i] >= 0) srow = conv_src_row_g(p.gather, p.pad_mode, p.stride, p.pad_left, conv_row_tin(p, rb[i]), rt[i], tap, ok, p.w_in, p.w_out, p.taps_h); \
     ptr = ok ? (A + (int64_t)conv_row_b(p, rb[i]) * p.a_batch_stride + (int64_t)srow * p.lda + lseg[i] * EPS) : (zline + lseg[i] * EPS); \
     inc = ok ? KC : 0;                                                                                  \
   }
@@ -619,7 +633,7 @@ __global__ __launch_bounds__(RNT, 2) void gemm_conv_ring_kernel(const ZsGemmConv
 #define ZS_SET_TAP(i, ptr, inc)                                                                         \
   {                                                                                                     \
     bool ok = false; int srow = 0;                                                                      \
-    if (rb[i] >= 0) srow = conv_src_row(p.gather, p.pad_mode, p.stride, p.pad_left, conv_row_tin(p, rb[i]), rt[i], tap, ok); \
+    if (rb[i] >= 0) srow = conv_src_row_g(p.gather, p.pad_mode, p.stride, p.pad_left, conv_row_tin(p, rb[i]), rt[i], tap, ok, p.w_in, p.w_out, p.taps_h); \
     ptr = ok ? (A + (int64_t)conv_row_b(p, rb[i]) * p.a_batch_stride + (int64_t)srow * p.lda + lseg[i] * EPS) : (zline + lseg[i] * EPS); \
     inc = ok ? KC : 0;                                                                                  \
   }
@@ -1116,7 +1130,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_conv_p8m16_kernel(const ZsGemmCon
 #define ZS_SET_TAP(i, ptr, inc)                                                                         \
   {                                                                                                     \
     bool ok = false; int srow = 0;                                                                      \
-    if (rb[i] >= 0) srow = conv_src_row(p.gather, p.pad_mode, p.stride, p.pad_left, conv_row_tin(p, rb[i]), rt[i], tap, ok); \
+    if (rb[i] >= 0) srow = conv_src_row_g(p.gather, p.pad_mode, p.stride, p.pad_left, conv_row_tin(p, rb[i]), rt[i], tap, ok, p.w_in, p.w_out, p.taps_h); \
     ptr = ok ? (A + (int64_t)conv_row_b(p, rb[i]) * p.a_batch_stride + (int64_t)srow * p.lda + lseg[i] * EPS) : (zline + lseg[i] * EPS); \
     inc = ok ? KC : 0;                                                                                  \
   }
@@ -1405,7 +1419,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_wgrad_kernel(const ZsGemmWgrad p, 
       vy[i] = make_uint4(0, 0, 0, 0); vx[i] = make_uint4(0, 0, 0, 0);
       if (m < mend) {
         if (cy < p.y_cols) vy[i] = *reinterpret_cast<const uint4*>(dY + (int64_t)m * p.ldy + cy);
-        bool ok; const int s = conv_src_row(0, p.pad_mode, p.stride, p.pad_left, p.T_in, lt[i], tap, ok);
+        bool ok; const int s = conv_src_row_g(0, p.pad_mode, p.stride, p.pad_left, p.T_in, lt[i], tap, ok, p.w_in, p.w_out, p.taps_h);
         if (ok && cx < p.x_cols)
           vx[i] = *reinterpret_cast<const uint4*>(X + (int64_t)lb[i] * p.x_batch_stride + (int64_t)s * p.ldx + cx);
       }
@@ -1579,7 +1593,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_wgrad_p8_kernel(const ZsGemmWgrad
     ok = false;
     if (m >= mend) return zline;
     const int b = m / p.T_out, t = m - b * p.T_out;
-    const int srow = conv_src_row(0, p.pad_mode, p.stride, p.pad_left, p.T_in, t, tap, ok);
+    const int srow = conv_src_row_g(0, p.pad_mode, p.stride, p.pad_left, p.T_in, t, tap, ok, p.w_in, p.w_out, p.taps_h);
     return X + (int64_t)b * p.x_batch_stride + (int64_t)srow * p.ldx;
   };
 
@@ -1909,7 +1923,18 @@ extern "C" int zs_gemm_conv(const ZsGemmConv* p, void* stream) {
   ZS_REQUIRE(aligned16(p->A) && aligned16(p->W) && (p->lda * es) % 16 == 0 && (p->a_batch_stride * es) % 16 == 0 &&
                  (p->a_gstride * es) % 16 == 0 && (p->w_gstride * es) % 16 == 0,
              "zs_gemm_conv: operands must be 16-byte aligned (A=%p lda=%lld)", p->A, (long long)p->lda);
-  if (p->gather == 0 && p->pad_mode == ZS_PAD_REFLECT) {
+  if (p->w_in > 0) {
+    ZS_REQUIRE(p->w_out > 0 && p->taps_h > 0 && p->taps % p->taps_h == 0 && p->T_in % p->w_in == 0 && p->T_out % p->w_out == 0 && !p->lengths,
+               "zs_gemm_conv: 2-D geometry (w_in %d, w_out %d, taps_h %d, taps %d, T_in %d, T_out %d)", p->w_in, p->w_out, p->taps_h, p->taps,
+               p->T_in, p->T_out);
+    if (p->gather == 0 && p->pad_mode == ZS_PAD_REFLECT) {
+      const int h_in = p->T_in / p->w_in, h_out = p->T_out / p->w_out, taps_w = p->taps / p->taps_h;
+      const int pr_h = (h_out - 1) * p->stride + p->taps_h - 1 - p->pad_left - (h_in - 1);
+      const int pr_w = (p->w_out - 1) * p->stride + taps_w - 1 - p->pad_left - (p->w_in - 1);
+      ZS_REQUIRE(p->pad_left < h_in && pr_h < h_in && p->pad_left < p->w_in && pr_w < p->w_in,
+                 "zs_gemm_conv: Padding size should be less than the corresponding input dimension (2-D: pad %d, H %d, W %d)", p->pad_left, h_in, p->w_in);
+    }
+  } else if (p->gather == 0 && p->pad_mode == ZS_PAD_REFLECT) {
     const int pad_r = (p->T_out - 1) * p->stride + p->taps - 1 - p->pad_left - (p->T_in - 1);
     ZS_REQUIRE(p->pad_left < p->T_in && pad_r < p->T_in,
                "zs_gemm_conv: Padding size should be less than the corresponding input dimension (pad %d/%d, T %d)",
@@ -2002,6 +2027,10 @@ extern "C" int zs_gemm_wgrad(const ZsGemmWgrad* p, void* stream) {
              "zs_gemm_wgrad: operands must be 16-byte aligned");
   ZS_REQUIRE(p->y_cols <= p->ldy && p->x_cols <= p->ldx && p->Cout <= p->y_cols && p->Cin <= p->x_cols, "zs_gemm_wgrad: column bounds");
   ZS_REQUIRE(!p->co_split2 || p->Cout % 2 == 0, "zs_gemm_wgrad: SPLIT2 needs even Cout");
+  ZS_REQUIRE(p->w_in == 0 || (p->w_in > 0 && p->w_out > 0 && p->taps_h > 0 && p->taps % p->taps_h == 0 && p->T_in % p->w_in == 0 &&
+                              p->T_out % p->w_out == 0),
+             "zs_gemm_wgrad: 2-D geometry (w_in %d, w_out %d, taps_h %d, taps %d, T_in %d, T_out %d)", p->w_in, p->w_out, p->taps_h, p->taps,
+             p->T_in, p->T_out);
   const WgradPlan w = wgrad_plan(p);
   const int splits = w.splits, co_tiles = w.co_tiles, ci_tiles = w.ci_tiles, cout_r = w.cout_r, cin_r = w.cin_r;
   const int rows_per_split = w.rows_per_split;

@@ -220,6 +220,62 @@ __global__ __launch_bounds__(NTP) void conv2d_fold_kernel(const ZsConv2dFold p) 
   }
 }
 
+// ---- un-padding of a parity-class data gradient (zs_conv2d_unpad) ---------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NTP) void conv2d_unpad_kernel(const ZsConv2dUnpad p) {
+  const int groups = (p.fill_cols + 7) / 8;
+  const int64_t total = (int64_t)p.B * p.H * p.W * groups;
+  const int Hc0 = (p.Hp + 1) >> 1, Hc1 = p.Hp >> 1, Wc0 = (p.Wp + 1) >> 1, Wc1 = p.Wp >> 1;
+  const void* const gq[4] = {p.g00, p.g01, p.g10, p.g11};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % groups);
+    const int64_t row = i / groups;
+    const int w = (int)(row % p.W);
+    const int64_t bh = row / p.W;
+    const int h = (int)(bh % p.H), b = (int)(bh / p.H);
+    const int c0 = g * 8;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (c0 < p.C) {
+      int hs[3], ws[3], nh = 0, nw = 0;
+      hs[nh++] = h;
+      ws[nw++] = w;
+      if (p.pad_mode == ZS_PAD_REFLECT) {
+        if (h >= 1 && h <= p.pad) hs[nh++] = -h;
+        if (h <= p.H - 2 && h >= p.H - 1 - p.pad) hs[nh++] = 2 * (p.H - 1) - h;
+        if (w >= 1 && w <= p.pad) ws[nw++] = -w;
+        if (w <= p.W - 2 && w >= p.W - 1 - p.pad) ws[nw++] = 2 * (p.W - 1) - w;
+      }
+      for (int a = 0; a < nh; ++a) {
+        const int hp = hs[a] + p.pad;
+        if (hp < 0 || hp >= p.Hp) continue;
+        const int ph = hp & 1, Hc = ph ? Hc1 : Hc0;
+        for (int q = 0; q < nw; ++q) {
+          const int wp = ws[q] + p.pad;
+          if (wp < 0 || wp >= p.Wp) continue;
+          const int pw = wp & 1, Wc = pw ? Wc1 : Wc0;
+          const T* src = (const T*)gq[2 * ph + pw] + (((int64_t)b * Hc + (hp >> 1)) * Wc + (wp >> 1)) * p.ldg + c0;
+          float v[8];
+          load8<T>(src, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+      }
+      if (p.add) {
+        float v[8];
+        load8<T>((const T*)p.add + row * p.ldadd + c0, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (c0 + e >= p.C) acc[e] = 0.f;
+    }
+    store8<T>((T*)p.out + row * p.ldo + c0, acc);
+  }
+}
+
 // ---- per-(b, c) moments over T rows --------------------------------------------------------------------------------------------
 // grid (C/64 chunks, B, slabs of MOM_ROWS rows); thread (cg = tid & 7, rg = tid >> 3): 8 channels of rows rg, rg + 32, ...
 template <typename T>
@@ -657,6 +713,21 @@ extern "C" int zs_conv2d_fold(const ZsConv2dFold* p, void* stream) {
   if (p->dtype == ZS_F32) hipLaunchKernelGGL(conv2d_fold_kernel<float>, dim3(grid_for(total)), dim3(NTP), 0, (hipStream_t)stream, *p);
   else hipLaunchKernelGGL(conv2d_fold_kernel<bf16_t>, dim3(grid_for(total)), dim3(NTP), 0, (hipStream_t)stream, *p);
   return zs_check_launch("zs_conv2d_fold");
+}
+
+extern "C" int zs_conv2d_unpad(const ZsConv2dUnpad* p, void* stream) {
+  ZS_REQUIRE(p && p->g00 && p->g01 && p->g10 && p->g11 && p->out, "zs_conv2d_unpad: null operand");
+  ZS_DT_OK(p);
+  ZS_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0 && p->C > 0 && p->pad >= 0 && p->Hp > p->pad && p->Wp > p->pad && p->Hp <= p->H + 2 * p->pad &&
+                 p->Wp <= p->W + 2 * p->pad, "zs_conv2d_unpad: sizes");
+  ZS_REQUIRE(p->pad_mode != ZS_PAD_REFLECT || (p->pad < p->H && p->pad < p->W), "zs_conv2d_unpad: Padding size should be less than the corresponding input dimension");
+  ZS_REQUIRE(p->C % 8 == 0 && p->ldg % 8 == 0 && p->ldg >= p->C && p->ldo % 8 == 0 && p->fill_cols % 8 == 0 && p->fill_cols >= p->C && p->ldo >= p->fill_cols &&
+                 al16p(p->g00) && al16p(p->g01) && al16p(p->g10) && al16p(p->g11) && al16p(p->out) && (!p->add || (al16p(p->add) && p->ldadd % 8 == 0)),
+             "zs_conv2d_unpad: C, row pitches and fill_cols must be multiples of 8, operands 16-byte aligned");
+  const int64_t total = (int64_t)p->B * p->H * p->W * (p->fill_cols / 8);
+  if (p->dtype == ZS_F32) hipLaunchKernelGGL(conv2d_unpad_kernel<float>, dim3(grid_for(total)), dim3(NTP), 0, (hipStream_t)stream, *p);
+  else hipLaunchKernelGGL(conv2d_unpad_kernel<bf16_t>, dim3(grid_for(total)), dim3(NTP), 0, (hipStream_t)stream, *p);
+  return zs_check_launch("zs_conv2d_unpad");
 }
 
 extern "C" size_t zs_row_moments_workspace(int32_t B, int32_t T, int32_t C) {

@@ -351,6 +351,105 @@ class ConvLayer(object):
         wgrad_call(c, kw, self.sid)
 
 
+class Conv2dLayer(object):
+    """nn.Conv2d [Cout, Cin, k, k] (stride 1 or 2, padding k // 2 by reflect or zero pad on both axes) on channels-last rows
+    [B, H*W, C], as ONE implicit GEMM per pass with 2-D taps in the kernels' row pointers (ZsGemmConv.w_in): no im2col buffer.
+    The weight's dims (2, 3) run along W and H of the rows layout (for the stage-2 critic: frequency and time), i.e. tap
+    j = kw*k + kh is the parameter's own flat order -- forward operand and weight gradient address the parameter directly.
+    Stride-2 data gradient by output parity in BOTH axes: four stride-1 transposed correlations (k = 5: 3x3, 3x2, 2x3, 2x2 taps) over
+    the padded input domain, one class buffer each, joined and un-padded by zs_conv2d_unpad."""
+
+    def __init__(self, ctx, weight, bias, gweight, gbias, stride=2, pad_mode=L.ZS_PAD_REFLECT, name=''):
+        self.ctx, self.name = ctx, name
+        self.w, self.b, self.gw, self.gb = weight, bias, gweight, gbias
+        self.Cout, self.Cin, self.k = weight.shape[0], weight.shape[1], weight.shape[2]
+        if weight.dim() != 4 or weight.shape[3] != self.k or stride not in (1, 2):
+            raise ValueError('Conv2dLayer: square kernels, stride 1 or 2')
+        self.stride, self.pad_mode, self.pad = stride, pad_mode, self.k // 2
+        self.taps = self.k * self.k
+        kc = ctx.kc
+        self.cin_pad, self.cout_pad = rup(self.Cin, kc), rup(self.Cout, kc)
+        self.ldw, self.n_pad, self.n_pad_d = self.taps * self.cin_pad, rup(self.Cout, 128), rup(self.Cin, 128)
+        dev, tdt = ctx.device, ctx.tdt
+        self.wf = torch.zeros(self.n_pad * self.ldw + SLACK, dtype=tdt, device=dev)
+        # data-gradient operands: per parity class (ph, pw) rows = input channels, K = (kw', kh') x cout_pad
+        self.nt = [(self.k + 1) // 2, self.k // 2] if stride == 2 else [self.k]
+        self.wd = {}
+        for ph in range(len(self.nt)):
+            for pw in range(len(self.nt)):
+                ld = self.nt[ph] * self.nt[pw] * self.cout_pad
+                self.wd[(ph, pw)] = (torch.zeros(self.n_pad_d * ld + SLACK, dtype=tdt, device=dev), ld)
+        self.sid = next_sid()
+
+    def out_hw(self, H, W):
+        return (H + 2 * self.pad - self.k) // self.stride + 1, (W + 2 * self.pad - self.k) // self.stride + 1
+
+    def pack(self):
+        c, k = self.ctx, self.k
+        common = dict(dtype=c.dt, so=self.Cin * self.taps, si=self.taps, Cout=self.Cout, Cin=self.Cin, co_split2=0)
+        L.call('zs_pack_weight', 'ZsPackWeight', c.stream, transpose=0, inner_pad=self.cin_pad, dst=L.ptr(self.wf), ldw=self.ldw,
+               n_rows=self.n_pad, n_cols=self.ldw, W=L.ptr(self.w), sj=1, taps=self.taps, **common)
+        step = self.stride
+        for (ph, pw), (buf, ld) in self.wd.items():
+            nh, nw = self.nt[ph], self.nt[pw]
+            for kwp in range(nw):                                 # real taps kw = pw + step*kw', kh = ph + step*kh'
+                L.call('zs_pack_weight', 'ZsPackWeight', c.stream, transpose=1, inner_pad=self.cout_pad, dst=L.ptr(buf), ldw=ld,
+                       n_rows=self.n_pad_d, n_cols=nh * self.cout_pad, col_offset=kwp * nh * self.cout_pad,
+                       W=L.ptr(self.w, (pw + step * kwp) * k + ph), sj=step, taps=nh, **common)
+
+    def fwd(self, X, H, W, out, act=L.ZS_ACT_NONE, slope=0.0, bias=True, out_f32=False):
+        """X: Act [B, H*W, Cin] -> out: Act [B, Ho*Wo, Cout].  Returns (Ho, Wo)."""
+        c = self.ctx
+        Ho, Wo = self.out_hw(H, W)
+        if X.T != H * W or out.T != Ho * Wo or X.B != out.B:
+            raise ValueError('Conv2dLayer.fwd: rows %d x %d for an image of %d x %d, output %d x %d' % (X.B, X.T, H, W, out.B, out.T))
+        L.call('zs_gemm_conv', 'ZsGemmConv', c.stream, dtype=c.dt, A=X.ptr(), lda=X.ld, a_batch_stride=X.T * X.ld, B=X.B, T_in=H * W,
+               T_out=Ho * Wo, taps=self.taps, stride=self.stride, pad_left=self.pad, pad_mode=self.pad_mode, gather=0, cin_pad=self.cin_pad,
+               W=L.ptr(self.wf), ldw=self.ldw, N=self.Cout, n_pad=self.n_pad, bias=(L.ptr(self.b) if (bias and self.b is not None) else None),
+               act=act, slope=slope, groups=1, out=out.ptr(), ldc=out.ld, out_f32=int(out_f32), store_mode=L.ZS_STORE_ROWS,
+               out_cols=min(out.cols, rup(self.Cout, 32)), w_in=W, w_out=Wo, taps_h=self.k)
+        return Ho, Wo
+
+    def wgrad(self, dY, X, H, W, accumulate=False, bias=True):
+        """gw (+)= dY^T * taps(X);  gb (+)= column sums of dY.  dY: Act [B, Ho*Wo, Cout]; X: Act [B, H*W, Cin]."""
+        c, es = self.ctx, self.ctx.es
+        Ho, Wo = self.out_hw(H, W)
+        kw = dict(dtype=c.dt, dY=dY.ptr(), ldy=dY.ld, y_cols=min(dY.cols, rup(self.Cout, 16 // es)), X=X.ptr(), ldx=X.ld,
+                  x_batch_stride=X.T * X.ld, x_cols=min(X.cols, rup(self.Cin, 16 // es)), B=X.B, T_in=H * W, T_out=Ho * Wo, taps=self.taps,
+                  stride=self.stride, pad_left=self.pad, pad_mode=self.pad_mode, Cout=self.Cout, Cin=self.Cin, dW=L.ptr(self.gw),
+                  so=self.Cin * self.taps, si=self.taps, sj=1, db=(L.ptr(self.gb) if bias else None), co_split2=0,
+                  accumulate=int(accumulate), splits=0, w_in=W, w_out=Wo, taps_h=self.k)
+        wgrad_call(c, kw, self.sid)
+
+    def padded_hw(self, H, W):
+        """Extent of the padded input domain the forward pass reads."""
+        Ho, Wo = self.out_hw(H, W)
+        return (Ho - 1) * self.stride + self.k, (Wo - 1) * self.stride + self.k
+
+    def dgrad(self, dY, H, W, out, name, add=None, fill_cols=None):
+        """dY: Act [B, Ho*Wo, Cout] -> out: Act [B, H*W, Cin] = gradient w.r.t. the layer input (+ add), stride 2."""
+        c = self.ctx
+        if self.stride != 2:
+            raise ValueError('Conv2dLayer.dgrad: stride 2 only')
+        Ho, Wo = self.out_hw(H, W)
+        Hp, Wp = self.padded_hw(H, W)
+        g = {}
+        for (ph, pw), (buf, ld) in self.wd.items():
+            Hc, Wc = (Hp - ph + 1) // 2, (Wp - pw + 1) // 2
+            gq = c.act('%s_q%d%d' % (name, ph, pw), dY.B, Hc * Wc, self.Cin)
+            L.call('zs_gemm_conv', 'ZsGemmConv', c.stream, dtype=c.dt, A=dY.ptr(), lda=dY.ld, a_batch_stride=dY.T * dY.ld, B=dY.B,
+                   T_in=Ho * Wo, T_out=Hc * Wc, taps=self.nt[ph] * self.nt[pw], stride=1, pad_left=0, pad_mode=L.ZS_PAD_ZERO, gather=1,
+                   cin_pad=self.cout_pad, W=L.ptr(buf), ldw=ld, N=self.Cin, n_pad=self.n_pad_d, act=L.ZS_ACT_NONE, out=gq.ptr(), ldc=gq.ld,
+                   out_cols=min(gq.cols, rup(self.Cin, 32)), store_mode=L.ZS_STORE_ROWS, groups=1, out_f32=0, w_in=Wo, w_out=Wc,
+                   taps_h=self.nt[ph])
+            g[(ph, pw)] = gq
+        g00 = g[(0, 0)]
+        L.call('zs_conv2d_unpad', 'ZsConv2dUnpad', c.stream, dtype=c.dt, g00=g00.ptr(), g01=g[(0, 1)].ptr(), g10=g[(1, 0)].ptr(),
+               g11=g[(1, 1)].ptr(), ldg=g00.ld, B=dY.B, H=H, W=W, C=rup(self.Cin, 8), Hp=Hp, Wp=Wp, pad=self.pad, pad_mode=self.pad_mode,
+               add=(add.ptr() if add is not None else None), ldadd=(add.ld if add is not None else 0), out=out.ptr(), ldo=out.ld,
+               fill_cols=(fill_cols if fill_cols is not None else out.ld))
+
+
 _SID = [0]
 
 
