@@ -59,17 +59,28 @@ __device__ __forceinline__ int conv_src_row(int gather, int pad_mode, int stride
 }
 
 // 2-D convolutions (ZsGemmConv.w_in > 0): a sample's rows are an H x w_in image, output position t = (t / w_out, t % w_out), tap
-// j = (kw, kh) = (j / taps_h, j % taps_h) -- the 1-D rule applied per axis (same stride, padding and pad mode on both).
+// j = (kw, kh) = (j / taps_h, j % taps_h) -- the 1-D rule applied per axis (same stride, padding and pad mode on both).  The two
+// divisions sit in the K loop (every tap change, every row): they are multiplications by 2^32 / d + 1, exact while the dividend
+// times the divisor stays below 2^32 (positions per sample x w_out, taps x taps_h: the host checks).
+struct Geom2 { int w_in, w_out, taps_h, h_in; unsigned mw, mt; };
+__device__ __forceinline__ Geom2 make_geom2(int w_in, int w_out, int taps_h, int T_in) {
+  Geom2 g;
+  g.w_in = w_in; g.w_out = w_out; g.taps_h = taps_h;
+  g.h_in = w_in > 0 ? T_in / w_in : 0;
+  g.mw = w_in > 0 ? 0xffffffffu / (unsigned)w_out + 1u : 0u;
+  g.mt = w_in > 0 ? 0xffffffffu / (unsigned)taps_h + 1u : 0u;
+  return g;
+}
 __device__ __forceinline__ int conv_src_row_g(int gather, int pad_mode, int stride, int pad_left, int T_in, int t, int j, bool& ok,
-                                              int w_in, int w_out, int taps_h) {
-  if (w_in == 0) return conv_src_row(gather, pad_mode, stride, pad_left, T_in, t, j, ok);
-  const int ho = t / w_out, wo = t - ho * w_out;
-  const int kw = j / taps_h, kh = j - kw * taps_h;
+                                              const Geom2& g) {
+  if (g.w_in == 0) return conv_src_row(gather, pad_mode, stride, pad_left, T_in, t, j, ok);
+  const int ho = g.w_out == 1 ? t : (int)__umulhi((unsigned)t, g.mw), wo = t - ho * g.w_out;          // (2^32 / 1 + 1 does not fit)
+  const int kw = g.taps_h == 1 ? j : (int)__umulhi((unsigned)j, g.mt), kh = j - kw * g.taps_h;
   bool ok_h, ok_w;
-  const int h = conv_src_row(gather, pad_mode, stride, pad_left, T_in / w_in, ho, kh, ok_h);
-  const int w = conv_src_row(gather, pad_mode, stride, pad_left, w_in, wo, kw, ok_w);
+  const int h = conv_src_row(gather, pad_mode, stride, pad_left, g.h_in, ho, kh, ok_h);
+  const int w = conv_src_row(gather, pad_mode, stride, pad_left, g.w_in, wo, kw, ok_w);
   ok = ok_h && ok_w;
-  return h * w_in + w;
+  return h * g.w_in + w;
 }
 
 // (sample, position) of output row m for the A-row loaders.  rb < 0: the row contributes zeros (beyond M, or beyond its sample's
@@ -318,6 +329,7 @@ __device__ __forceinline__ void epilogue_finish(const ZsGemmConv& p, const float
 
 template <typename T>
 __global__ __launch_bounds__(NT, 2) void gemm_conv_kernel(const ZsGemmConv p) {
+  const Geom2 g2 = make_geom2(p.w_in, p.w_out, p.taps_h, p.T_in);
   constexpr int EPS = 16 / (int)sizeof(T);    // elements per 16-byte segment
   constexpr int KC = ROWB / (int)sizeof(T);   // elements per K chunk
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -360,7 +372,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_conv_kernel(const ZsGemmConv p) {
 #define ZS_SET_TAP(i, ptr, inc)                                                                         \
   {                                                                                                     \
     bool ok = false; int srow = 0;                                                                      \
-    if (rb[i] >= 0) srow = conv_src_row_g(p.gather, p.pad_mode, p.stride, p.pad_left, conv_row_tin(p, rb[i]), rt[i], tap, ok, p.w_in, p.w_out, p.taps_h); \
+    if (rb[i] >= 0) srow = conv_src_row_g(p.gather, p.pad_mode, p.stride, p.pad_left, conv_row_tin(p, rb[i]), rt[i], tap, ok, g2); \
     ptr = ok ? (A + (int64_t)conv_row_b(p, rb[i]) * p.a_batch_stride + (int64_t)srow * p.lda + seg * EPS) : zline;       \
     inc = ok ? KC : 0;                                                                                  \
   }
@@ -461,6 +473,7 @@ constexpr int DTILE = 128 * 128;   // bytes per operand tile
 
 template <typename T>
 __global__ __launch_bounds__(NT, 2) void gemm_conv_dma_kernel(const ZsGemmConv p) {
+  const Geom2 g2 = make_geom2(p.w_in, p.w_out, p.taps_h, p.T_in);
   constexpr int EPS = 16 / (int)sizeof(T);
   constexpr int KC = ROWB / (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -500,7 +513,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_conv_dma_kernel(const ZsGemmConv p
 #define ZS_SET_TAP(i, ptr, inc)                                                                         \
   {                                                                                                     \
     bool ok = false; int srow = 0;                                                                      \
-    if (rb[i] >= 0) srow = conv_src_row_g(p.gather, p.pad_mode, p.stride, p.pad_left, conv_row_tin(p, rb[i]), rt[i], tap, ok, p.w_in, p.w_out, p.taps_h); \
+    if (rb[i] >= 0) srow = conv_src_row_g(p.gather, p.pad_mode, p.stride, p.pad_left, conv_row_tin(p, rb[i]), rt[i], tap, ok, g2); \
     ptr = ok ? (A + (int64_t)conv_row_b(p, rb[i]) * p.a_batch_stride + (int64_t)srow * p.lda + lseg[i] * EPS) : (zline + lseg[i] * EPS); \
     inc = ok ? KC : 0;                                                                                  \
   }
@@ -597,6 +610,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
 template <typename T, int PP>
 __global__ __launch_bounds__(RNT, 2) void gemm_conv_ring_kernel(const ZsGemmConv p) {
+  const Geom2 g2 = make_geom2(p.w_in, p.w_out, p.taps_h, p.T_in);
   constexpr int EPS = 16 / (int)sizeof(T);
   constexpr int KC = ROWB / (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -633,7 +647,7 @@ __global__ __launch_bounds__(RNT, 2) void gemm_conv_ring_kernel(const ZsGemmConv
 #define ZS_SET_TAP(i, ptr, inc)                                                                         \
   {                                                                                                     \
     bool ok = false; int srow = 0;                                                                      \
-    if (rb[i] >= 0) srow = conv_src_row_g(p.gather, p.pad_mode, p.stride, p.pad_left, conv_row_tin(p, rb[i]), rt[i], tap, ok, p.w_in, p.w_out, p.taps_h); \
+    if (rb[i] >= 0) srow = conv_src_row_g(p.gather, p.pad_mode, p.stride, p.pad_left, conv_row_tin(p, rb[i]), rt[i], tap, ok, g2); \
     ptr = ok ? (A + (int64_t)conv_row_b(p, rb[i]) * p.a_batch_stride + (int64_t)srow * p.lda + lseg[i] * EPS) : (zline + lseg[i] * EPS); \
     inc = ok ? KC : 0;                                                                                  \
   }
@@ -1092,6 +1106,7 @@ __device__ __forceinline__ void p8_regs_epilogue(const ZsGemmConv& p, f32x4_m (&
 
 template <typename T>
 __global__ __launch_bounds__(PNT, 2) void gemm_conv_p8m16_kernel(const ZsGemmConv p) {
+  const Geom2 g2 = make_geom2(p.w_in, p.w_out, p.taps_h, p.T_in);
   constexpr int EPS = 16 / (int)sizeof(T);
   constexpr int KC = ROWB / (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1130,7 +1145,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_conv_p8m16_kernel(const ZsGemmCon
 #define ZS_SET_TAP(i, ptr, inc)                                                                         \
   {                                                                                                     \
     bool ok = false; int srow = 0;                                                                      \
-    if (rb[i] >= 0) srow = conv_src_row_g(p.gather, p.pad_mode, p.stride, p.pad_left, conv_row_tin(p, rb[i]), rt[i], tap, ok, p.w_in, p.w_out, p.taps_h); \
+    if (rb[i] >= 0) srow = conv_src_row_g(p.gather, p.pad_mode, p.stride, p.pad_left, conv_row_tin(p, rb[i]), rt[i], tap, ok, g2); \
     ptr = ok ? (A + (int64_t)conv_row_b(p, rb[i]) * p.a_batch_stride + (int64_t)srow * p.lda + lseg[i] * EPS) : (zline + lseg[i] * EPS); \
     inc = ok ? KC : 0;                                                                                  \
   }
@@ -1367,6 +1382,7 @@ template <> struct WFrag<bf16_t> {
 template <typename T>
 __global__ __launch_bounds__(NT, 2) void gemm_wgrad_kernel(const ZsGemmWgrad p, int ci_tiles, int rows_per_split,
                                                           int cout_r, int cin_r) {
+  const Geom2 g2 = make_geom2(p.w_in, p.w_out, p.taps_h, p.T_in);
   constexpr int EPS = 16 / (int)sizeof(T);
   constexpr int SPR = 128 / EPS;               // 16-B segments per 128-element row
   constexpr int LPT = (WK * SPR) / NT;         // loads per thread per operand (2 bf16, 4 fp32)
@@ -1419,7 +1435,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_wgrad_kernel(const ZsGemmWgrad p, 
       vy[i] = make_uint4(0, 0, 0, 0); vx[i] = make_uint4(0, 0, 0, 0);
       if (m < mend) {
         if (cy < p.y_cols) vy[i] = *reinterpret_cast<const uint4*>(dY + (int64_t)m * p.ldy + cy);
-        bool ok; const int s = conv_src_row_g(0, p.pad_mode, p.stride, p.pad_left, p.T_in, lt[i], tap, ok, p.w_in, p.w_out, p.taps_h);
+        bool ok; const int s = conv_src_row_g(0, p.pad_mode, p.stride, p.pad_left, p.T_in, lt[i], tap, ok, g2);
         if (ok && cx < p.x_cols)
           vx[i] = *reinterpret_cast<const uint4*>(X + (int64_t)lb[i] * p.x_batch_stride + (int64_t)s * p.ldx + cx);
       }
@@ -1554,6 +1570,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_wgrad_kernel(const ZsGemmWgrad p, 
 
 __global__ __launch_bounds__(PNT, 2) void gemm_wgrad_p8_kernel(const ZsGemmWgrad p, int ci_tiles, int rows_per_split,
                                                               int cout_r, int cin_r) {
+  const Geom2 g2 = make_geom2(p.w_in, p.w_out, p.taps_h, p.T_in);
   typedef bf16_t T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -1593,7 +1610,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_wgrad_p8_kernel(const ZsGemmWgrad
     ok = false;
     if (m >= mend) return zline;
     const int b = m / p.T_out, t = m - b * p.T_out;
-    const int srow = conv_src_row_g(0, p.pad_mode, p.stride, p.pad_left, p.T_in, t, tap, ok, p.w_in, p.w_out, p.taps_h);
+    const int srow = conv_src_row_g(0, p.pad_mode, p.stride, p.pad_left, p.T_in, t, tap, ok, g2);
     return X + (int64_t)b * p.x_batch_stride + (int64_t)srow * p.ldx;
   };
 
@@ -1924,6 +1941,7 @@ extern "C" int zs_gemm_conv(const ZsGemmConv* p, void* stream) {
                  (p->a_gstride * es) % 16 == 0 && (p->w_gstride * es) % 16 == 0,
              "zs_gemm_conv: operands must be 16-byte aligned (A=%p lda=%lld)", p->A, (long long)p->lda);
   if (p->w_in > 0) {
+    ZS_REQUIRE((int64_t)p->T_out * p->w_out < (1ll << 32), "zs_gemm_conv: 2-D image too large (T_out %d x w_out %d)", p->T_out, p->w_out);
     ZS_REQUIRE(p->w_out > 0 && p->taps_h > 0 && p->taps % p->taps_h == 0 && p->T_in % p->w_in == 0 && p->T_out % p->w_out == 0 && !p->lengths,
                "zs_gemm_conv: 2-D geometry (w_in %d, w_out %d, taps_h %d, taps %d, T_in %d, T_out %d)", p->w_in, p->w_out, p->taps_h, p->taps,
                p->T_in, p->T_out);
@@ -2028,7 +2046,7 @@ extern "C" int zs_gemm_wgrad(const ZsGemmWgrad* p, void* stream) {
   ZS_REQUIRE(p->y_cols <= p->ldy && p->x_cols <= p->ldx && p->Cout <= p->y_cols && p->Cin <= p->x_cols, "zs_gemm_wgrad: column bounds");
   ZS_REQUIRE(!p->co_split2 || p->Cout % 2 == 0, "zs_gemm_wgrad: SPLIT2 needs even Cout");
   ZS_REQUIRE(p->w_in == 0 || (p->w_in > 0 && p->w_out > 0 && p->taps_h > 0 && p->taps % p->taps_h == 0 && p->T_in % p->w_in == 0 &&
-                              p->T_out % p->w_out == 0),
+                              p->T_out % p->w_out == 0 && (int64_t)p->T_out * p->w_out < (1ll << 32)),
              "zs_gemm_wgrad: 2-D geometry (w_in %d, w_out %d, taps_h %d, taps %d, T_in %d, T_out %d)", p->w_in, p->w_out, p->taps_h, p->taps,
              p->T_in, p->T_out);
   const WgradPlan w = wgrad_plan(p);

@@ -357,9 +357,15 @@ class Conv2dLayer(object):
     The weight's dims (2, 3) run along W and H of the rows layout (for the stage-2 critic: frequency and time), i.e. tap
     j = kw*k + kh is the parameter's own flat order -- forward operand and weight gradient address the parameter directly.
     Stride-2 data gradient by output parity in BOTH axes: four stride-1 transposed correlations (k = 5: 3x3, 3x2, 2x3, 2x2 taps) over
-    the padded input domain, one class buffer each, joined and un-padded by zs_conv2d_unpad."""
+    the padded input domain, one class buffer each, joined and un-padded by zs_conv2d_unpad.
+    Measured against the stage-2 critic's gathered path (im2col along H + Conv1d over W; tools/conv2d_bench.py, B = 128, bf16, us,
+    gathered path incl. its gather / fold kernels in brackets): forward layer 2..5: 536 (476), 414 (361), 420 (375), 200 (224);
+    data gradient 1092 (1027), 519 (583), 483 (568), 255 (400); weight gradient layer 2: 1052 (817).  The pointer arithmetic of
+    a tap change (every 128-byte chunk at C = 64) and the half-empty 128-column tiles at C = 64 cost more than the im2col traffic
+    saves, and in the D step the 2-D data gradients of layers 3-5 gave 31.3 against 30.9 ms: zs_amd.patch keeps the gathered
+    path; this class is the tested entry to the 2-D mode of the kernels (tests/test_gpu_kernels.py::test_conv2d_layer_vs_torch)."""
 
-    def __init__(self, ctx, weight, bias, gweight, gbias, stride=2, pad_mode=L.ZS_PAD_REFLECT, name=''):
+    def __init__(self, ctx, weight, bias, gweight, gbias, stride=2, pad_mode=L.ZS_PAD_REFLECT, name='', dgrad_only=False):
         self.ctx, self.name = ctx, name
         self.w, self.b, self.gw, self.gb = weight, bias, gweight, gbias
         self.Cout, self.Cin, self.k = weight.shape[0], weight.shape[1], weight.shape[2]
@@ -371,7 +377,7 @@ class Conv2dLayer(object):
         self.cin_pad, self.cout_pad = rup(self.Cin, kc), rup(self.Cout, kc)
         self.ldw, self.n_pad, self.n_pad_d = self.taps * self.cin_pad, rup(self.Cout, 128), rup(self.Cin, 128)
         dev, tdt = ctx.device, ctx.tdt
-        self.wf = torch.zeros(self.n_pad * self.ldw + SLACK, dtype=tdt, device=dev)
+        self.wf = None if dgrad_only else torch.zeros(self.n_pad * self.ldw + SLACK, dtype=tdt, device=dev)      # forward operand
         # data-gradient operands: per parity class (ph, pw) rows = input channels, K = (kw', kh') x cout_pad
         self.nt = [(self.k + 1) // 2, self.k // 2] if stride == 2 else [self.k]
         self.wd = {}
@@ -387,8 +393,9 @@ class Conv2dLayer(object):
     def pack(self):
         c, k = self.ctx, self.k
         common = dict(dtype=c.dt, so=self.Cin * self.taps, si=self.taps, Cout=self.Cout, Cin=self.Cin, co_split2=0)
-        L.call('zs_pack_weight', 'ZsPackWeight', c.stream, transpose=0, inner_pad=self.cin_pad, dst=L.ptr(self.wf), ldw=self.ldw,
-               n_rows=self.n_pad, n_cols=self.ldw, W=L.ptr(self.w), sj=1, taps=self.taps, **common)
+        if self.wf is not None:
+            L.call('zs_pack_weight', 'ZsPackWeight', c.stream, transpose=0, inner_pad=self.cin_pad, dst=L.ptr(self.wf), ldw=self.ldw,
+                   n_rows=self.n_pad, n_cols=self.ldw, W=L.ptr(self.w), sj=1, taps=self.taps, **common)
         step = self.stride
         for (ph, pw), (buf, ld) in self.wd.items():
             nh, nw = self.nt[ph], self.nt[pw]
@@ -401,6 +408,8 @@ class Conv2dLayer(object):
         """X: Act [B, H*W, Cin] -> out: Act [B, Ho*Wo, Cout].  Returns (Ho, Wo)."""
         c = self.ctx
         Ho, Wo = self.out_hw(H, W)
+        if self.wf is None:
+            raise ValueError('Conv2dLayer.fwd: built with dgrad_only')
         if X.T != H * W or out.T != Ho * Wo or X.B != out.B:
             raise ValueError('Conv2dLayer.fwd: rows %d x %d for an image of %d x %d, output %d x %d' % (X.B, X.T, H, W, out.B, out.T))
         L.call('zs_gemm_conv', 'ZsGemmConv', c.stream, dtype=c.dt, A=X.ptr(), lda=X.ld, a_batch_stride=X.T * X.ld, B=X.B, T_in=H * W,
