@@ -513,6 +513,35 @@ typedef struct {
   int32_t full;                                   /* transpose of zs_conv2d_gather(full): gp rows (b, ho, wo), columns (kh*k + kw)*C + c */
 } ZsConv2dFold;
 int zs_conv2d_fold(const ZsConv2dFold* p, void* stream);
+/* zs_conv1_fwd: the critic's FIRST Conv2d (one input channel, k x k taps, k*k <= 32, stride 2, padding k/2) computed directly from
+ * the fp32 image: every lane of a wave builds its 8 bf16 im2col values (tap order kh*k + kw, as zs_conv2d_gather(full)) from the
+ * image and one 16x16x32 MFMA per 16 output channels does the rest -- the [B*Ho*Wo][64] im2col buffer (12.8 x the image) is
+ * neither written nor read:  out[(b, ho, wo)][co] = act(bias[co] + sum_{kh, kw} W[co][kh*k + kw] * bf16(x[b][refl(2ho + kh - k/2)][refl(2wo + kw - k/2)])).
+ * bf16 only (the fp32 path keeps zs_conv2d_gather(full) + zs_gemm_conv); Cout a multiple of 16, <= 64 per launch column block. */
+typedef struct {
+  const float* x;                                 /* [B][H][W] */
+  const void* W; int64_t ldw;                     /* bf16 [>= Cout][ldw], ldw >= 32, columns >= k*k are zeros (ConvLayer.wf of the layer) */
+  const float* bias; int32_t act; float slope;    /* bias may be null; ZS_ACT_NONE / ZS_ACT_LRELU */
+  void* out; int64_t ldo;                         /* bf16 [B*Ho*Wo][ldo] */
+  int32_t B, H, Wd, Cout, k, pad_mode;
+} ZsConv1Fwd;
+int zs_conv1_fwd(const ZsConv1Fwd* p, void* stream);
+/* zs_conv1_wgrad: weight and bias gradient of the same layer, again straight from the image (the im2col column of a position is
+ * rebuilt in registers as the MFMA's B operand, the A operand is gz transposed):
+ *   dW[co][kh*k + kw] (+)= sum_m gz[m][co] * bf16(x[...]),  db[co] (+)= sum_m gz[m][co]        (m over all B*Ho*Wo positions)
+ * Positions are dealt to the waves of a fixed grid in a fixed order, each workgroup leaves one partial [64][32] in `workspace`,
+ * a second kernel sums them in workgroup order: no atomics, bitwise reproducible.  bf16 gz; Cout a multiple of 16, <= 64. */
+typedef struct {
+  const float* x;                                 /* [B][H][W] */
+  const void* gz; int64_t ldg;                    /* bf16 [B*Ho*Wo][ldg] */
+  float* dW; int64_t lddw;                        /* fp32 [Cout][lddw], lddw >= k*k */
+  float* db;                                      /* optional fp32 [Cout] */
+  int32_t accumulate;
+  int32_t B, H, Wd, Cout, k, pad_mode;
+  float* workspace; size_t workspace_bytes;       /* >= zs_conv1_wgrad_workspace() bytes */
+} ZsConv1Wgrad;
+size_t zs_conv1_wgrad_workspace(void);
+int zs_conv1_wgrad(const ZsConv1Wgrad* p, void* stream);
 /* zs_conv2d_unpad: the last step of a stride-2 Conv2d's data gradient computed by output parity (ZsGemmConv with w_in > 0,
  * gather 1): class (ph, pw) holds the gradient at the positions (2 h2 + ph, 2 w2 + pw) of the PADDED input domain
  * [Hp][Wp] as rows [B][Hc(ph) * Wc(pw)], Hc(ph) = (Hp - ph + 1) / 2, Wc(pw) = (Wp - pw + 1) / 2.  This kernel removes the

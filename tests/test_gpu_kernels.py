@@ -835,3 +835,83 @@ def test_conv2d_layer_vs_torch(zs, dtype, case, gemm_variant):
     torch.cuda.synchronize()
     _close('conv2d dx + add', dx.valid(), x.grad.reshape(B, H * W, Cin) + 1.0, tol)
     _close('conv2d dW accumulated', lay.gw, 2 * wr.grad, tol)
+
+
+@pytest.mark.parametrize('case', [(2, 12, 17, 64, 5, True), (3, 128, 513, 64, 5, True), (2, 9, 20, 32, 3, False), (1, 16, 33, 16, 5, True)])
+def test_conv1_fwd_direct_vs_torch_and_im2col_path(zs, case):
+    """zs_conv1_fwd (the critic's first Conv2d straight from the fp32 image, bf16 MFMA) against torch's conv2d on bf16-rounded
+    operands (fp32 accumulation: 1e-5 of scale before the output's own bf16 rounding) and against the im2col + GEMM path it
+    replaces (same rounding of the operands: equal up to the accumulation order, well inside one bf16 ulp of the output scale)."""
+    L, layers = zs
+    B, H, W, Cout, k, reflect = case
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(B, H, W, generator=g)
+    w = torch.randn(Cout, 1, k, k, generator=g) / k                                # [co, 1, kw, kh]
+    b = torch.randn(Cout, generator=g)
+    p = k // 2
+    xr, wr = x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float()
+    xp = F.pad(xr[:, None].permute(0, 1, 3, 2), (p, p, p, p), mode='reflect' if reflect else 'constant')      # [B, 1, W, H]
+    y = F.leaky_relu(F.conv2d(xp, wr, b, stride=2), 0.01).permute(0, 3, 2, 1)                                   # [B, Ho, Wo, Cout]
+    ctx = _ctx(layers, 'bf16')
+    dev = ctx.device
+    Ho, Wo = y.shape[1], y.shape[2]
+    # the layer's virtual Linear weight [Cout, kh*k + kw] and its packed forward operand
+    wv = w[:, 0].permute(0, 2, 1).reshape(Cout, k * k).contiguous().to(dev)
+    lay = layers.ConvLayer(ctx, wv, b.to(dev), torch.zeros_like(wv), torch.zeros(Cout, device=dev))
+    lay.pack()
+    xd = x.to(dev).contiguous()
+    out = ctx.act('c1o', B * Ho, Wo, Cout)
+    pm = L.ZS_PAD_REFLECT if reflect else L.ZS_PAD_ZERO
+    L.call('zs_conv1_fwd', 'ZsConv1Fwd', ctx.stream, x=L.ptr(xd), W=L.ptr(lay.wf), ldw=lay.ldw, bias=L.ptr(lay.b), act=L.ZS_ACT_LRELU, slope=0.01,
+           out=out.ptr(), ldo=out.ld, B=B, H=H, Wd=W, Cout=Cout, k=k, pad_mode=pm)
+    # the path it replaces
+    xh = ctx.act('c1xh', B * Ho, Wo, k * k, ld=lay.cin_pad)
+    L.call('zs_conv2d_gather', 'ZsConv2dGather', ctx.stream, dtype=ctx.dt, x=L.ptr(xd), ldx=1, x_f32=1, out=xh.ptr(), ldo=xh.ld, B=B, H_in=H,
+           H_out=Ho, Wd=W, C=1, k=k, stride=2, pad=p, pad_mode=pm, full=1)
+    ref = ctx.act('c1r', B * Ho, Wo, Cout)
+    lay.fwd(xh, out=ref, act=L.ZS_ACT_LRELU, slope=0.01)
+    torch.cuda.synchronize()
+    got = out.valid().float().cpu().reshape(B, Ho, Wo, Cout)
+    _close('conv1 direct vs torch', got, y, 1e-2)
+    _close('conv1 direct vs im2col path', got, ref.valid().float().cpu().reshape(B, Ho, Wo, Cout), 8e-3)
+    assert (got == ref.valid().float().cpu().reshape(B, Ho, Wo, Cout)).float().mean().item() > 0.98
+
+
+@pytest.mark.parametrize('case', [(2, 12, 17, 64, 5, True), (3, 64, 257, 64, 5, True), (2, 9, 20, 32, 3, False), (1, 16, 33, 16, 5, True)])
+def test_conv1_wgrad_direct_vs_torch(zs, case):
+    """zs_conv1_wgrad (weight + bias gradient of the critic's first Conv2d straight from the fp32 image) against autograd on the
+    bf16-rounded operands; accumulate adds; two runs are bitwise equal (fixed tile -> wave assignment, fixed-order reduction)."""
+    L, layers = zs
+    B, H, W, Cout, k, reflect = case
+    g = torch.Generator().manual_seed(10)
+    x = torch.rand(B, H, W, generator=g)
+    p = k // 2
+    xr = x.to(torch.bfloat16).float()
+    w = (torch.randn(Cout, 1, k, k, generator=g) / k).requires_grad_(True)
+    b = torch.zeros(Cout, requires_grad=True)
+    xp = F.pad(xr[:, None].permute(0, 1, 3, 2), (p, p, p, p), mode='reflect' if reflect else 'constant')
+    y = F.conv2d(xp, w, b, stride=2).permute(0, 3, 2, 1)                           # [B, Ho, Wo, Cout]
+    dy = torch.randn(y.shape, generator=g).to(torch.bfloat16).float()
+    y.backward(dy)
+    ref_w = w.grad[:, 0].permute(0, 2, 1).reshape(Cout, k * k)                   # [co][kh*k + kw]
+    ctx = _ctx(layers, 'bf16')
+    dev = ctx.device
+    Ho, Wo = y.shape[1], y.shape[2]
+    gz = _to_act(layers, ctx, 'c1gz', dy.reshape(B * Ho, Wo, Cout))
+    xd = x.to(dev).contiguous()
+    dW, db = torch.zeros(Cout, k * k, device=dev), torch.zeros(Cout, device=dev)
+    ws = torch.empty(L.lib().zs_conv1_wgrad_workspace() // 4, device=dev)
+    kw = dict(x=L.ptr(xd), gz=gz.ptr(), ldg=gz.ld, dW=L.ptr(dW), lddw=k * k, db=L.ptr(db), B=B, H=H, Wd=W, Cout=Cout, k=k,
+              pad_mode=(L.ZS_PAD_REFLECT if reflect else L.ZS_PAD_ZERO), workspace=L.ptr(ws), workspace_bytes=ws.numel() * 4)
+    L.call('zs_conv1_wgrad', 'ZsConv1Wgrad', ctx.stream, accumulate=0, **kw)
+    torch.cuda.synchronize()
+    first = (dW.clone(), db.clone())
+    _close('conv1 dW', dW, ref_w, 2e-3)
+    _close('conv1 db', db, b.grad, 2e-3)
+    L.call('zs_conv1_wgrad', 'ZsConv1Wgrad', ctx.stream, accumulate=0, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(dW, first[0]) and torch.equal(db, first[1])
+    L.call('zs_conv1_wgrad', 'ZsConv1Wgrad', ctx.stream, accumulate=1, **kw)
+    torch.cuda.synchronize()
+    _close('conv1 dW accumulated', dW, 2 * ref_w, 2e-3)
+    _close('conv1 db accumulated', db, 2 * b.grad, 2e-3)

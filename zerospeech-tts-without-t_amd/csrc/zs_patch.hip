@@ -107,6 +107,166 @@ __global__ __launch_bounds__(NTP) void conv2d_im2col_kernel(const ZsConv2dGather
   }
 }
 
+// The first layer without the im2col buffer (zs_conv1_fwd): a wave = 16 consecutive output positions x all (<= 64) output channels.
+// MFMA operands: A = weight rows (physical row i of channel tile t is channel 16 (i / 4) + 4 t + i % 4, so that a lane ends up with
+// 16 CONSECUTIVE channels of its position), B = the im2col column of the lane's position, 8 taps per lane gathered from the image.
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const ZsConv1Fwd p, int Ho, int Wo, int64_t M) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 16 + j;
+  // weight fragments and bias of this lane's channels
+  uint4 wfr[4];
+  float bs[16];
+  const bf16_t* Wb = (const bf16_t*)p.W;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int ch = 16 * (j >> 2) + 4 * t + (j & 3);                              // A-operand row j of tile t
+    wfr[t] = ch < p.Cout ? *reinterpret_cast<const uint4*>(Wb + (int64_t)ch * p.ldw + 8 * q) : make_uint4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) bs[e] = (p.bias != nullptr && 16 * q + e < p.Cout) ? p.bias[16 * q + e] : 0.f;
+  // the lane's position and its 8 taps k = 8 q + e
+  const int64_t mc = m < M ? m : M - 1;
+  const int wo = (int)(mc % Wo);
+  const int64_t bh = mc / Wo;
+  const int ho = (int)(bh % Ho), b = (int)(bh / Ho);
+  const float* xb = p.x + (int64_t)b * p.H * p.Wd;
+  const int pad = p.k >> 1, kk = p.k * p.k;
+  float xv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int tap = 8 * q + e;
+    const int kh = tap / p.k, kw = tap - kh * p.k;
+    bool vh, vw;
+    const int hi = pad_index(2 * ho + kh - pad, p.H, p.pad_mode, vh);
+    const int wi = pad_index(2 * wo + kw - pad, p.Wd, p.pad_mode, vw);
+    xv[e] = (tap < kk && vh && vw) ? xb[(int64_t)hi * p.Wd + wi] : 0.f;
+  }
+  uint4 bfr;
+  bfr.x = (uint32_t)f2bf(xv[0]) | ((uint32_t)f2bf(xv[1]) << 16);
+  bfr.y = (uint32_t)f2bf(xv[2]) | ((uint32_t)f2bf(xv[3]) << 16);
+  bfr.z = (uint32_t)f2bf(xv[4]) | ((uint32_t)f2bf(xv[5]) << 16);
+  bfr.w = (uint32_t)f2bf(xv[6]) | ((uint32_t)f2bf(xv[7]) << 16);
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfr[t]), __builtin_bit_cast(bf16x8, bfr), acc[t], 0, 0, 0);
+  }
+  if (m >= M || 16 * q >= p.Cout) return;
+  // acc[t][r] = channel 16 q + 4 t + r of position j
+  float o[16];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = acc[t][r] + bs[4 * t + r];
+      if (p.act == ZS_ACT_LRELU) v = lrelu_f(v, p.slope);
+      o[4 * t + r] = v;
+    }
+  bf16_t* dst = (bf16_t*)p.out + m * p.ldo + 16 * q;
+  float lo[8], hi[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { lo[e] = o[e]; hi[e] = o[8 + e]; }
+  store8<bf16_t>(dst, lo);
+  store8<bf16_t>(dst + 8, hi);
+}
+
+// Weight gradient of the first layer without the im2col buffer (zs_conv1_wgrad).  K of the MFMA = positions: a wave takes tiles of
+// 32 positions (lane (j, q): positions 8 q .. 8 q + 7 of the tile); A = gz transposed (row = channel 16 ct + j), B = the im2col
+// columns (column = tap 16 kt + j; tap k*k is a column of ones: its result row is the bias gradient).
+constexpr int C1W_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const ZsConv1Wgrad p, int Ho, int Wo, int64_t M) {
+  __shared__ float red[4][64 * 32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int pad = p.k >> 1, kk = p.k * p.k;
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) acc[ct][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // this lane's two taps
+  int kh[2], kw[2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) { const int tap = 16 * kt + j; kh[kt] = tap / p.k; kw[kt] = tap - kh[kt] * p.k; }
+  const bf16_t* gz = (const bf16_t*)p.gz;
+  const int64_t n_tiles = (M + 31) / 32;
+  const int64_t per_wave = (n_tiles + (int64_t)C1W_BLOCKS * 4 - 1) / ((int64_t)C1W_BLOCKS * 4);
+  const int64_t t_lo = ((int64_t)blockIdx.x * 4 + wave) * per_wave, t_hi = min(n_tiles, t_lo + per_wave);      // contiguous, fixed
+  for (int64_t tile = t_lo; tile < t_hi; ++tile) {
+    const int64_t m0 = tile * 32 + 8 * q;
+    // (b, ho, wo) of the lane's first position, then incremented
+    int64_t mm = m0 < M ? m0 : M - 1;
+    int wo = (int)(mm % Wo);
+    int64_t bh = mm / Wo;
+    int ho = (int)(bh % Ho), b = (int)(bh / Ho);
+    float av[4][8], bv[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool in = m0 + e < M;
+      const bf16_t* row = gz + (m0 + e) * p.ldg;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) av[ct][e] = (in && 16 * ct + j < p.Cout) ? bf2f(row[16 * ct + j]) : 0.f;
+      const float* xb = p.x + (int64_t)b * p.H * p.Wd;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const int tap = 16 * kt + j;
+        float v = 0.f;
+        if (in && tap < kk) {
+          bool vh, vw;
+          const int hi = pad_index(2 * ho + kh[kt] - pad, p.H, p.pad_mode, vh);
+          const int wi = pad_index(2 * wo + kw[kt] - pad, p.Wd, p.pad_mode, vw);
+          if (vh && vw) v = xb[(int64_t)hi * p.Wd + wi];
+        } else if (in && tap == kk) v = 1.f;                                   // the bias column
+        bv[kt][e] = v;
+      }
+      if (++wo == Wo) { wo = 0; if (++ho == Ho) { ho = 0; ++b; } }
+    }
+    uint4 af[4], bf_[2];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      af[ct].x = (uint32_t)f2bf(av[ct][0]) | ((uint32_t)f2bf(av[ct][1]) << 16); af[ct].y = (uint32_t)f2bf(av[ct][2]) | ((uint32_t)f2bf(av[ct][3]) << 16);
+      af[ct].z = (uint32_t)f2bf(av[ct][4]) | ((uint32_t)f2bf(av[ct][5]) << 16); af[ct].w = (uint32_t)f2bf(av[ct][6]) | ((uint32_t)f2bf(av[ct][7]) << 16);
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      bf_[kt].x = (uint32_t)f2bf(bv[kt][0]) | ((uint32_t)f2bf(bv[kt][1]) << 16); bf_[kt].y = (uint32_t)f2bf(bv[kt][2]) | ((uint32_t)f2bf(bv[kt][3]) << 16);
+      bf_[kt].z = (uint32_t)f2bf(bv[kt][4]) | ((uint32_t)f2bf(bv[kt][5]) << 16); bf_[kt].w = (uint32_t)f2bf(bv[kt][6]) | ((uint32_t)f2bf(bv[kt][7]) << 16);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+        acc[ct][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[ct]), __builtin_bit_cast(bf16x8, bf_[kt]), acc[ct][kt], 0, 0, 0);
+  }
+  // acc[ct][kt][r] = (channel 16 ct + 4 q + r, tap 16 kt + j): waves summed in wave order, one partial per workgroup
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][(16 * ct + 4 * q + r) * 32 + 16 * kt + j] = acc[ct][kt][r];
+  __syncthreads();
+  float* out = p.workspace + (int64_t)blockIdx.x * (64 * 32);
+  for (int i = threadIdx.x; i < 64 * 32; i += 256) out[i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+}
+
+__global__ __launch_bounds__(256) void conv1_wgrad_reduce_kernel(const ZsConv1Wgrad p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;                                // (channel, tap slot)
+  if (i >= 64 * 32) return;
+  const int co = i >> 5, tap = i & 31, kk = p.k * p.k;
+  if (co >= p.Cout || tap > kk) return;
+  float s = 0.f;
+  for (int w = 0; w < C1W_BLOCKS; ++w) s += p.workspace[(int64_t)w * (64 * 32) + i];
+  if (tap < kk) {
+    float* d = p.dW + (int64_t)co * p.lddw + tap;
+    *d = p.accumulate ? *d + s : s;
+  } else if (p.db != nullptr) {
+    p.db[co] = p.accumulate ? p.db[co] + s : s;
+  }
+}
+
 // transpose of the above (ZsConv2dFold.full): dX[b, hi, w, c] = sum over (ph in {hi, reflection partners}, kh -> ho) x
 // (pw in {w, reflection partners}, kw -> wo) of gp[(b, ho, wo), (kh*k + kw)*C + c]; one thread per (b, hi, w, c), fixed order
 template <typename T>
@@ -690,6 +850,40 @@ extern "C" int zs_conv2d_gather(const ZsConv2dGather* p, void* stream) {
   if (p->dtype == ZS_F32) hipLaunchKernelGGL(conv2d_gather_kernel<float>, dim3(grid_for(total)), dim3(NTP), 0, (hipStream_t)stream, *p);
   else hipLaunchKernelGGL(conv2d_gather_kernel<bf16_t>, dim3(grid_for(total)), dim3(NTP), 0, (hipStream_t)stream, *p);
   return zs_check_launch("zs_conv2d_gather");
+}
+
+extern "C" int zs_conv1_fwd(const ZsConv1Fwd* p, void* stream) {
+  ZS_REQUIRE(p && p->x && p->W && p->out, "zs_conv1_fwd: null operand");
+  ZS_REQUIRE(p->B > 0 && p->H > 0 && p->Wd > 0 && p->k > 0 && (p->k & 1) && p->k * p->k <= 32 && p->Cout > 0 && p->Cout % 16 == 0 && p->Cout <= 64,
+             "zs_conv1_fwd: sizes (odd k with k*k <= 32, Cout a multiple of 16 <= 64)");
+  ZS_REQUIRE(p->ldw >= 32 && p->ldw % 8 == 0 && al16p(p->W) && al16p(p->out) && p->ldo % 8 == 0 && p->ldo >= p->Cout, "zs_conv1_fwd: alignment / pitches");
+  ZS_REQUIRE(p->act == ZS_ACT_NONE || p->act == ZS_ACT_LRELU, "zs_conv1_fwd: act");
+  const int pad = p->k / 2;
+  ZS_REQUIRE(p->pad_mode != ZS_PAD_REFLECT || (pad < p->H && pad < p->Wd), "zs_conv1_fwd: Padding size should be less than the corresponding input dimension");
+  const int Ho = (p->H + 2 * pad - p->k) / 2 + 1, Wo = (p->Wd + 2 * pad - p->k) / 2 + 1;
+  const int64_t M = (int64_t)p->B * Ho * Wo;
+  const int64_t blocks = (M + 63) / 64;
+  ZS_REQUIRE(blocks < (1ll << 31), "zs_conv1_fwd: grid too large");
+  hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *p, Ho, Wo, M);
+  return zs_check_launch("zs_conv1_fwd");
+}
+
+extern "C" size_t zs_conv1_wgrad_workspace(void) { return (size_t)C1W_BLOCKS * 64 * 32 * sizeof(float); }
+
+extern "C" int zs_conv1_wgrad(const ZsConv1Wgrad* p, void* stream) {
+  ZS_REQUIRE(p && p->x && p->gz && p->dW && p->workspace, "zs_conv1_wgrad: null operand");
+  ZS_REQUIRE(p->B > 0 && p->H > 0 && p->Wd > 0 && p->k > 0 && (p->k & 1) && p->k * p->k < 32 && p->Cout > 0 && p->Cout % 16 == 0 && p->Cout <= 64,
+             "zs_conv1_wgrad: sizes (odd k with k*k < 32, Cout a multiple of 16 <= 64)");
+  ZS_REQUIRE(p->ldg >= p->Cout && p->lddw >= p->k * p->k && p->workspace_bytes >= zs_conv1_wgrad_workspace(), "zs_conv1_wgrad: pitches / workspace");
+  const int pad = p->k / 2;
+  ZS_REQUIRE(p->pad_mode != ZS_PAD_REFLECT || (pad < p->H && pad < p->Wd), "zs_conv1_wgrad: Padding size should be less than the corresponding input dimension");
+  const int Ho = (p->H + 2 * pad - p->k) / 2 + 1, Wo = (p->Wd + 2 * pad - p->k) / 2 + 1;
+  const int64_t M = (int64_t)p->B * Ho * Wo;
+  hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(C1W_BLOCKS), dim3(256), 0, (hipStream_t)stream, *p, Ho, Wo, M);
+  int rc = zs_check_launch("zs_conv1_wgrad");
+  if (rc) return rc;
+  hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, *p);
+  return zs_check_launch("zs_conv1_wgrad.reduce");
 }
 
 extern "C" int zs_conv2d_fold(const ZsConv2dFold* p, void* stream) {

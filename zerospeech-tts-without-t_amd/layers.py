@@ -467,41 +467,45 @@ def next_sid():
     return _SID[0]
 
 
+def side_launch(ctx, sid, need):
+    """Where a weight-gradient launch goes: (stream handle, workspace of >= need bytes).  With ctx.overlap_wgrad a side stream made
+    to wait for everything enqueued so far on the main stream (dY and X are complete), asynchronous from then on; the launches of one
+    side stream serialise, so they share that stream's workspace.  sid: None = round robin over the side streams; with
+    ctx.pin_wgrad_streams an int pins the call to side stream sid % N (every weight gradient of one parameter on ONE stream:
+    accumulating launches are ordered behind each other)."""
+    if not ctx.overlap_wgrad:
+        return ctx.stream, ctx.workspace(need)
+    sd = side_stream(ctx.device)
+    if sid is not None and ctx.pin_wgrad_streams:
+        i = sid % len(sd['streams'])
+    else:
+        i = sd['next']                               # plain round robin (measured: 1 stream 13.7 ms/step, 3: 13.5, 4: 13.0,
+        sd['next'] = (i + 1) % len(sd['streams'])    # 8: 13.05; big GEMMs pinned to one stream: 13.55)
+    ws = sd['ws'][i]
+    if ws is None or ws.numel() < need:
+        # growth (first steps only): every side stream gets a workspace of the new size, so that no later launch --
+        # in particular none inside a hipGraph capture -- has to grow one
+        if any(w is not None for w in sd['ws']):
+            torch.cuda.synchronize(ctx.device)      # the streams may still be using the old buffers
+        size = int(need * 1.25) + 1024
+        sd['ws'] = [torch.empty(size, dtype=torch.uint8, device=ctx.device) for _ in sd['streams']]
+        ws = sd['ws'][i]
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(ctx.device))
+    sd['streams'][i].wait_event(ev)
+    sd['used'] = True
+    return sd['streams'][i].cuda_stream, ws
+
+
 def wgrad_call(ctx, kw, sid=None):
-    """sid: None = round robin over the side streams; with ctx.pin_wgrad_streams an int pins the call to side stream sid % N
-    (every weight gradient of one parameter on ONE stream: accumulating launches are ordered behind each other)."""
+    """zs_gemm_wgrad through side_launch()."""
     S = L.STRUCTS['ZsGemmWgrad']
     s = S()
     for k, v in kw.items():
         if v is not None:
             setattr(s, k, v)
     need = L.lib().zs_gemm_wgrad_workspace_bytes(ctypes.byref(s))
-    stream = ctx.stream
-    if ctx.overlap_wgrad:
-        # ordered after everything enqueued so far on the main stream (dY and X are complete), then asynchronous;
-        # the weight gradients of one side stream serialise, so they share that stream's split-K workspace
-        sd = side_stream(ctx.device)
-        if sid is not None and ctx.pin_wgrad_streams:
-            i = sid % len(sd['streams'])
-        else:
-            i = sd['next']                               # plain round robin (measured: 1 stream 13.7 ms/step, 3: 13.5, 4: 13.0,
-            sd['next'] = (i + 1) % len(sd['streams'])    # 8: 13.05; big GEMMs pinned to one stream: 13.55)
-        ws = sd['ws'][i]
-        if ws is None or ws.numel() < need:
-            # growth (first steps only): every side stream gets a workspace of the new size, so that no later launch --
-            # in particular none inside a hipGraph capture -- has to grow one
-            if any(w is not None for w in sd['ws']):
-                torch.cuda.synchronize(ctx.device)      # the streams may still be using the old buffers
-            size = int(need * 1.25) + 1024
-            sd['ws'] = [torch.empty(size, dtype=torch.uint8, device=ctx.device) for _ in sd['streams']]
-            ws = sd['ws'][i]
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(ctx.device))
-        sd['streams'][i].wait_event(ev)
-        sd['used'] = True
-        stream = sd['streams'][i].cuda_stream
-    else:
-        ws = ctx.workspace(need)
+    stream, ws = side_launch(ctx, sid, need)
     s.workspace = ws.data_ptr()
     s.workspace_bytes = ws.numel()
     L.check(L.lib().zs_gemm_wgrad(ctypes.byref(s), ctypes.c_void_p(stream)), 'zs_gemm_wgrad')

@@ -18,10 +18,11 @@ import torch.nn as nn
 from . import _lib as L
 import os
 
-from .layers import Act, ConvLayer, Ctx, join_side, rup
+from .layers import Act, ConvLayer, Ctx, join_side, rup, side_launch
 from .model import ZsModule
 
 LRELU = L.ZS_ACT_LRELU
+DIRECT_CONV1 = os.environ.get('ZS_PATCH_CONV1_DIRECT', '1') == '1'
 EPS_IN = 1e-5
 _UID = [0]
 
@@ -215,6 +216,30 @@ class PatchEngine(object):
         L.call('zs_conv2d_gather', 'ZsConv2dGather', c.stream, dtype=c.dt, x=x_ptr, ldx=ldx, x_f32=int(x_f32), out=out.ptr(), ldo=out.ld,
                B=B, H_in=Hin, H_out=Hout, Wd=Wd, C=C, k=5, stride=2, pad=2, pad_mode=self.pad_mode, full=int(full))
 
+    def _conv1_ok(self, cl, src_f32):
+        c = self.ctx
+        return (DIRECT_CONV1 and getattr(cl, 'full', False) and src_f32 and c.dtype_name == 'bf16' and cl.C == 1 and cl.Cout % 16 == 0
+                and cl.Cout <= 64 and cl.kf == cl.kt and cl.kf * cl.kt < 32)
+
+    def _conv1_wgrad(self, cl, img_ptr, gz, B, H, W, bias=True):
+        """Accumulating weight (+ bias) gradient of the first layer straight from the image (zs_conv1_wgrad), on the layer's side stream."""
+        c, lay = self.ctx, cl.layer
+        stream, ws = side_launch(c, lay.sid, L.lib().zs_conv1_wgrad_workspace())
+        L.call('zs_conv1_wgrad', 'ZsConv1Wgrad', stream, x=img_ptr, gz=gz.ptr(), ldg=gz.ld, dW=L.ptr(lay.gw), lddw=lay.gw.shape[1],
+               db=(L.ptr(lay.gb) if bias else None), accumulate=1, B=B, H=H, Wd=W, Cout=cl.Cout, k=cl.kf, pad_mode=self.pad_mode,
+               workspace=ws.data_ptr(), workspace_bytes=ws.numel())
+
+    def _conv1_direct(self, cl, src_ptr, src_f32, B, H, W, out, act, slope, bias):
+        """First layer straight from the fp32 image (zs_conv1_fwd: bf16, one input channel, <= 64 output channels): the 25-column
+        im2col buffer is then only the weight gradient's operand.  Returns False where the GEMM over the im2col rows has to run."""
+        c = self.ctx
+        if not self._conv1_ok(cl, src_f32):
+            return False
+        lay = cl.layer
+        L.call('zs_conv1_fwd', 'ZsConv1Fwd', c.stream, x=src_ptr, W=L.ptr(lay.wf), ldw=lay.ldw, bias=(L.ptr(lay.b) if bias else None), act=act,
+               slope=slope, out=out.ptr(), ldo=out.ld, B=B, H=H, Wd=W, Cout=cl.Cout, k=cl.kf, pad_mode=self.pad_mode)
+        return True
+
     def _gathered(self, cl, name, B, H, W, C):
         """The im2col buffer of layer `cl` for an input of [B, H, W, C]: rows (b, ho) x W with 5C columns, or -- first layer --
         rows (b, ho) x W_out with all 25 C columns."""
@@ -250,14 +275,18 @@ class PatchEngine(object):
         H, W, C = T, F, 1
         src_ptr, src_ld, src_f32 = L.ptr(x_btf), 1, True
         for i in range(6):
+            img = None
             if i < 5:
                 cl = self.convs[i]
                 Ho, Wo = _half(H), _half(W)
-                xh = self._gathered(cl, self._name(key, 'xh%d' % i, B, H, W), B, H, W, C)
-                self._gather(src_ptr, src_ld, src_f32, B, H, Ho, W, C, xh, full=getattr(cl, 'full', False))
                 Cout = cl.Cout
                 y = c.act(self._name(key, 'y%d' % i, B, H, W), B * Ho, Wo, Cout)
-                cl.layer.fwd(xh, out=y, act=LRELU, slope=ns)
+                if i == 0 and self._conv1_direct(cl, src_ptr, src_f32, B, H, W, y, LRELU, ns, True):
+                    xh, img = None, src_ptr              # no im2col buffer: forward and weight gradient read the image itself
+                else:
+                    xh = self._gathered(cl, self._name(key, 'xh%d' % i, B, H, W), B, H, W, C)
+                    self._gather(src_ptr, src_ld, src_f32, B, H, Ho, W, C, xh, full=getattr(cl, 'full', False))
+                    cl.layer.fwd(xh, out=y, act=LRELU, slope=ns)
                 layer, xin = cl.layer, xh
             else:
                 Ho, Wo, Cout = H, W, self.conv6.Cout
@@ -280,7 +309,7 @@ class PatchEngine(object):
             a = c.act(self._name(key, 'a%d' % i, B, H, W), B, Tn, Cout)
             L.call('zs_in2d_fwd', 'ZsIn2dFwd', c.stream, dtype=c.dt, y=yv.ptr(), ldy=yv.ld, a=a.ptr(), lda=a.ld, mean=L.ptr(mean),
                    rstd=L.ptr(rstd), dm=L.ptr(dm), B=B, T=Tn, C=Cout)
-            tp['layers'].append(dict(layer=layer, xin=xin, y=yv, a=a, rstd=rstd, dm=dm, H=H, W=W, C=C, Ho=Ho, Wo=Wo, Cout=Cout, Tn=Tn))
+            tp['layers'].append(dict(layer=layer, xin=xin, img=img, y=yv, a=a, rstd=rstd, dm=dm, H=H, W=W, C=C, Ho=Ho, Wo=Wo, Cout=Cout, Tn=Tn))
             prev_a = Act(a.t, B * Ho, Wo, Cout, a.ld)             # rows view for the next conv / linear
             src_ptr, src_ld, src_f32 = a.ptr(), a.ld, False
             H, W, C = Ho, Wo, Cout
@@ -329,11 +358,18 @@ class PatchEngine(object):
             gz = g_in
             gzr = Act(gz.t, B * Ld['Ho'], Ld['Wo'], Ld['Cout'], gz.ld)
             if param_grads:
-                Ld['layer'].wgrad(gzr, Ld['xin'], accumulate=True)
+                self._wgrad(i, Ld, gz, gzr, Ld['xin'], Ld['img'])
             if i == 0 and not need_dx:
                 break
             g_in, dx = self._dgrad(key, 'b', i, Ld, gzr, None)
         return dx
+
+    def _wgrad(self, i, Ld, gz, gz_rows, xin, img, bias=True):
+        """Accumulating weight gradient of layer i: from the gathered rows `xin`, or (first layer, direct) from the image `img`."""
+        if img is not None:
+            self._conv1_wgrad(self.convs[i], img, gz, gz.B, Ld['H'], Ld['W'], bias=bias)
+        else:
+            Ld['layer'].wgrad(gz_rows, xin, accumulate=True, bias=bias)
 
     def _in_bwd(self, key, tag, i, Ld, ga, S2x, keep):
         """InstanceNorm2d + Dropout2d + LeakyReLU backward of layer i: ga (gradient w.r.t. a) -> gz (w.r.t. the conv output)."""
@@ -397,7 +433,9 @@ class PatchEngine(object):
             H, W, C, Ho, Wo, Cout, Tn = Ld['H'], Ld['W'], Ld['C'], Ld['Ho'], Ld['Wo'], Ld['Cout'], Ld['Tn']
             gbz = c.act(self._name(key, 'gbz%d' % i, B), B * Ho, Wo, Cout)
             gz_rows = Act(Ld['gz'].t, B * Ho, Wo, Cout, Ld['gz'].ld)
-            if i < 5:
+            if i == 0 and self._conv1_direct(self.convs[i], src_ptr, src_f32, B, H, W, gbz, L.ZS_ACT_NONE, 0.0, False):
+                self._conv1_wgrad(self.convs[i], src_ptr, Ld['gz'], B, H, W, bias=False)
+            elif i < 5:
                 xh = self._gathered(self.convs[i], self._name(key, 'gxh%d' % i, B), B, H, W, C)
                 self._gather(src_ptr, src_ld, src_f32, B, H, Ho, W, C, xh, full=getattr(self.convs[i], 'full', False))
                 Ld['layer'].fwd(xh, out=gbz, bias=False)
@@ -428,7 +466,7 @@ class PatchEngine(object):
             ga = Ld['xba'] if incoming is None else incoming           # incoming already holds dgrad + xba (fold / dgrad epilogue)
             zb = self._in_bwd(key, 'r', i, Ld, ga, Ld['A3'], False)
             zbr = Act(zb.t, B * Ld['Ho'], Ld['Wo'], Ld['Cout'], zb.ld)
-            Ld['layer'].wgrad(zbr, Ld['xin'], accumulate=True)
+            self._wgrad(i, Ld, zb, zbr, Ld['xin'], Ld['img'])
             if i == 0:
                 break
             incoming, _ = self._dgrad(key, 'r', i, Ld, zbr, tp['layers'][i - 1]['xba'])
