@@ -110,10 +110,10 @@ __global__ __launch_bounds__(NTP) void conv2d_im2col_kernel(const ZsConv2dGather
 // The first layer without the im2col buffer (zs_conv1_fwd): a wave = 16 consecutive output positions x all (<= 64) output channels.
 // MFMA operands: A = weight rows (physical row i of channel tile t is channel 16 (i / 4) + 4 t + i % 4, so that a lane ends up with
 // 16 CONSECUTIVE channels of its position), B = the im2col column of the lane's position, 8 taps per lane gathered from the image.
+constexpr int C1F_TPW = 8;                                                          // 16-position tiles per wave (weights loaded once)
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const ZsConv1Fwd p, int Ho, int Wo, int64_t M) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
-  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 16 + j;
   // weight fragments and bias of this lane's channels
   uint4 wfr[4];
   float bs[16];
@@ -125,89 +125,110 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const ZsConv1Fwd p, int 
   }
 #pragma unroll
   for (int e = 0; e < 16; ++e) bs[e] = (p.bias != nullptr && 16 * q + e < p.Cout) ? p.bias[16 * q + e] : 0.f;
-  // the lane's position and its 8 taps k = 8 q + e
-  const int64_t mc = m < M ? m : M - 1;
-  const int wo = (int)(mc % Wo);
-  const int64_t bh = mc / Wo;
-  const int ho = (int)(bh % Ho), b = (int)(bh / Ho);
-  const float* xb = p.x + (int64_t)b * p.H * p.Wd;
   const int pad = p.k >> 1, kk = p.k * p.k;
-  float xv[8];
+  int khs[8], kws[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int tap = 8 * q + e;
-    const int kh = tap / p.k, kw = tap - kh * p.k;
-    bool vh, vw;
-    const int hi = pad_index(2 * ho + kh - pad, p.H, p.pad_mode, vh);
-    const int wi = pad_index(2 * wo + kw - pad, p.Wd, p.pad_mode, vw);
-    xv[e] = (tap < kk && vh && vw) ? xb[(int64_t)hi * p.Wd + wi] : 0.f;
-  }
-  uint4 bfr;
-  bfr.x = (uint32_t)f2bf(xv[0]) | ((uint32_t)f2bf(xv[1]) << 16);
-  bfr.y = (uint32_t)f2bf(xv[2]) | ((uint32_t)f2bf(xv[3]) << 16);
-  bfr.z = (uint32_t)f2bf(xv[4]) | ((uint32_t)f2bf(xv[5]) << 16);
-  bfr.w = (uint32_t)f2bf(xv[6]) | ((uint32_t)f2bf(xv[7]) << 16);
-  f32x4 acc[4];
+  for (int e = 0; e < 8; ++e) { const int tap = 8 * q + e; khs[e] = tap / p.k; kws[e] = tap - khs[e] * p.k; }
+  const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wave) * C1F_TPW;
+#pragma unroll 2
+  for (int it = 0; it < C1F_TPW; ++it) {
+    const int64_t m = (tile0 + it) * 16 + j;
+    if ((tile0 + it) * 16 >= M) break;                                           // (wave-uniform)
+    // the lane's position and its 8 taps k = 8 q + e
+    const int mc = (int)(m < M ? m : M - 1);                                     // (M < 2^31: host check; 32-bit divisions)
+    const int bh = mc / Wo, wo = mc - bh * Wo;
+    const int b = bh / Ho, ho = bh - b * Ho;
+    const float* xb = p.x + (int64_t)b * p.H * p.Wd;
+    float xv[8];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfr[t]), __builtin_bit_cast(bf16x8, bfr), acc[t], 0, 0, 0);
-  }
-  if (m >= M || 16 * q >= p.Cout) return;
-  // acc[t][r] = channel 16 q + 4 t + r of position j
-  float o[16];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v = acc[t][r] + bs[4 * t + r];
-      if (p.act == ZS_ACT_LRELU) v = lrelu_f(v, p.slope);
-      o[4 * t + r] = v;
+    for (int e = 0; e < 8; ++e) {
+      bool vh, vw;
+      const int hi = pad_index(2 * ho + khs[e] - pad, p.H, p.pad_mode, vh);
+      const int wi = pad_index(2 * wo + kws[e] - pad, p.Wd, p.pad_mode, vw);
+      xv[e] = (8 * q + e < kk && vh && vw) ? xb[(int64_t)hi * p.Wd + wi] : 0.f;
     }
-  bf16_t* dst = (bf16_t*)p.out + m * p.ldo + 16 * q;
-  float lo[8], hi[8];
+    uint4 bfr;
+    bfr.x = (uint32_t)f2bf(xv[0]) | ((uint32_t)f2bf(xv[1]) << 16);
+    bfr.y = (uint32_t)f2bf(xv[2]) | ((uint32_t)f2bf(xv[3]) << 16);
+    bfr.z = (uint32_t)f2bf(xv[4]) | ((uint32_t)f2bf(xv[5]) << 16);
+    bfr.w = (uint32_t)f2bf(xv[6]) | ((uint32_t)f2bf(xv[7]) << 16);
+    f32x4 acc[4];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { lo[e] = o[e]; hi[e] = o[8 + e]; }
-  store8<bf16_t>(dst, lo);
-  store8<bf16_t>(dst + 8, hi);
+    for (int t = 0; t < 4; ++t) {
+      acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfr[t]), __builtin_bit_cast(bf16x8, bfr), acc[t], 0, 0, 0);
+    }
+    if (m >= M || 16 * q >= p.Cout) continue;
+    // acc[t][r] = channel 16 q + 4 t + r of position j
+    float lo[8], hi[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[t][r] + bs[4 * t + r];
+        if (p.act == ZS_ACT_LRELU) v = lrelu_f(v, p.slope);
+        if (t < 2) lo[4 * t + r] = v; else hi[4 * (t - 2) + r] = v;
+      }
+    bf16_t* dst = (bf16_t*)p.out + m * p.ldo + 16 * q;
+    store8<bf16_t>(dst, lo);
+    store8<bf16_t>(dst + 8, hi);
+  }
 }
 
 // Weight gradient of the first layer without the im2col buffer (zs_conv1_wgrad).  K of the MFMA = positions: a wave takes tiles of
 // 32 positions (lane (j, q): positions 8 q .. 8 q + 7 of the tile); A = gz transposed (row = channel 16 ct + j), B = the im2col
 // columns (column = tap 16 kt + j; tap k*k is a column of ones: its result row is the bias gradient).
 constexpr int C1W_BLOCKS = 1024;
+constexpr int C1W_PITCH = 68;                                                       // bf16 elements per staged gz row (136 B: the four
+                                                                                    // 8-row groups of a fragment read land on banks 16 apart)
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const ZsConv1Wgrad p, int Ho, int Wo, int64_t M) {
   __shared__ float red[4][64 * 32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
   const int pad = p.k >> 1, kk = p.k * p.k;
+  // the wave's staging tile of gz ([32 positions][64 channels] bf16) lives in its slice of `red` until the final reduction
+  bf16_t* st = reinterpret_cast<bf16_t*>(&red[wave][0]);
   f32x4 acc[4][2];
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) acc[ct][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // this lane's two taps
   int kh[2], kw[2];
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt) { const int tap = 16 * kt + j; kh[kt] = tap / p.k; kw[kt] = tap - kh[kt] * p.k; }
   const bf16_t* gz = (const bf16_t*)p.gz;
+  const bool vec = (p.Cout == 64) && ((p.ldg & 7) == 0) && ((((uintptr_t)p.gz) & 15) == 0);
   const int64_t n_tiles = (M + 31) / 32;
   const int64_t per_wave = (n_tiles + (int64_t)C1W_BLOCKS * 4 - 1) / ((int64_t)C1W_BLOCKS * 4);
   const int64_t t_lo = ((int64_t)blockIdx.x * 4 + wave) * per_wave, t_hi = min(n_tiles, t_lo + per_wave);      // contiguous, fixed
   for (int64_t tile = t_lo; tile < t_hi; ++tile) {
-    const int64_t m0 = tile * 32 + 8 * q;
-    // (b, ho, wo) of the lane's first position, then incremented
-    int64_t mm = m0 < M ? m0 : M - 1;
-    int wo = (int)(mm % Wo);
-    int64_t bh = mm / Wo;
-    int ho = (int)(bh % Ho), b = (int)(bh / Ho);
-    float av[4][8], bv[2][8];
+    const int64_t mt = tile * 32;
+    // stage the tile: lane l loads 16-byte pieces (row l / 8 + 8 i, channels 8 (l % 8) ..): coalesced 128-byte rows
+    if (vec) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = (lane >> 3) + 8 * i, c8 = (lane & 7) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (mt + r < M) v = *reinterpret_cast<const uint4*>(gz + (mt + r) * p.ldg + c8);
+        *reinterpret_cast<uint2*>(st + r * C1W_PITCH + c8) = make_uint2(v.x, v.y);
+        *reinterpret_cast<uint2*>(st + r * C1W_PITCH + c8 + 4) = make_uint2(v.z, v.w);
+      }
+    } else {
+      for (int i = lane; i < 32 * 64; i += 64) {
+        const int r = i >> 6, cc = i & 63;
+        st[r * C1W_PITCH + cc] = (mt + r < M && cc < p.Cout) ? gz[(mt + r) * p.ldg + cc] : (bf16_t)0;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const int64_t m0 = mt + 8 * q;
+    const int mm = (int)(m0 < M ? m0 : M - 1);                                  // (M < 2^31: host check; 32-bit divisions)
+    int bh = mm / Wo, wo = mm - bh * Wo;
+    int b = bh / Ho, ho = bh - b * Ho;
+    float bv[2][8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const bool in = m0 + e < M;
-      const bf16_t* row = gz + (m0 + e) * p.ldg;
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) av[ct][e] = (in && 16 * ct + j < p.Cout) ? bf2f(row[16 * ct + j]) : 0.f;
       const float* xb = p.x + (int64_t)b * p.H * p.Wd;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
@@ -226,8 +247,13 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const ZsConv1Wgrad p, 
     uint4 af[4], bf_[2];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
-      af[ct].x = (uint32_t)f2bf(av[ct][0]) | ((uint32_t)f2bf(av[ct][1]) << 16); af[ct].y = (uint32_t)f2bf(av[ct][2]) | ((uint32_t)f2bf(av[ct][3]) << 16);
-      af[ct].z = (uint32_t)f2bf(av[ct][4]) | ((uint32_t)f2bf(av[ct][5]) << 16); af[ct].w = (uint32_t)f2bf(av[ct][6]) | ((uint32_t)f2bf(av[ct][7]) << 16);
+      uint32_t w4[4];
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        const uint32_t a0 = st[(8 * q + 2 * e2) * C1W_PITCH + 16 * ct + j], a1 = st[(8 * q + 2 * e2 + 1) * C1W_PITCH + 16 * ct + j];
+        w4[e2] = a0 | (a1 << 16);
+      }
+      af[ct] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
     }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -239,7 +265,10 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const ZsConv1Wgrad p, 
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
         acc[ct][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[ct]), __builtin_bit_cast(bf16x8, bf_[kt]), acc[ct][kt], 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();                                           // the next tile's staging overwrites what was just read
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
   // acc[ct][kt][r] = (channel 16 ct + 4 q + r, tap 16 kt + j): waves summed in wave order, one partial per workgroup
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct)
@@ -252,13 +281,21 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const ZsConv1Wgrad p, 
   for (int i = threadIdx.x; i < 64 * 32; i += 256) out[i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
 }
 
+// 64 workgroups x 32 outputs: thread (output o, eighth g) sums 128 partials in order, the eighths are combined in order
 __global__ __launch_bounds__(256) void conv1_wgrad_reduce_kernel(const ZsConv1Wgrad p) {
-  const int i = blockIdx.x * 256 + threadIdx.x;                                // (channel, tap slot)
-  if (i >= 64 * 32) return;
+  __shared__ float part[8][32];
+  const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + o;                                           // (channel, tap slot)
+  float s = 0.f;
+  for (int w = g * (C1W_BLOCKS / 8); w < (g + 1) * (C1W_BLOCKS / 8); ++w) s += p.workspace[(int64_t)w * (64 * 32) + i];
+  part[g][o] = s;
+  __syncthreads();
+  if (g != 0) return;
+  s = part[0][o];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) s += part[k][o];
   const int co = i >> 5, tap = i & 31, kk = p.k * p.k;
   if (co >= p.Cout || tap > kk) return;
-  float s = 0.f;
-  for (int w = 0; w < C1W_BLOCKS; ++w) s += p.workspace[(int64_t)w * (64 * 32) + i];
   if (tap < kk) {
     float* d = p.dW + (int64_t)co * p.lddw + tap;
     *d = p.accumulate ? *d + s : s;
@@ -862,8 +899,8 @@ extern "C" int zs_conv1_fwd(const ZsConv1Fwd* p, void* stream) {
   ZS_REQUIRE(p->pad_mode != ZS_PAD_REFLECT || (pad < p->H && pad < p->Wd), "zs_conv1_fwd: Padding size should be less than the corresponding input dimension");
   const int Ho = (p->H + 2 * pad - p->k) / 2 + 1, Wo = (p->Wd + 2 * pad - p->k) / 2 + 1;
   const int64_t M = (int64_t)p->B * Ho * Wo;
-  const int64_t blocks = (M + 63) / 64;
-  ZS_REQUIRE(blocks < (1ll << 31), "zs_conv1_fwd: grid too large");
+  const int64_t blocks = (M + 64 * C1F_TPW - 1) / (64 * C1F_TPW);
+  ZS_REQUIRE(M < (1ll << 31) - 64 * C1F_TPW, "zs_conv1_fwd: too many output positions");
   hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *p, Ho, Wo, M);
   return zs_check_launch("zs_conv1_fwd");
 }
@@ -879,10 +916,11 @@ extern "C" int zs_conv1_wgrad(const ZsConv1Wgrad* p, void* stream) {
   ZS_REQUIRE(p->pad_mode != ZS_PAD_REFLECT || (pad < p->H && pad < p->Wd), "zs_conv1_wgrad: Padding size should be less than the corresponding input dimension");
   const int Ho = (p->H + 2 * pad - p->k) / 2 + 1, Wo = (p->Wd + 2 * pad - p->k) / 2 + 1;
   const int64_t M = (int64_t)p->B * Ho * Wo;
+  ZS_REQUIRE(M < (1ll << 31) - 64, "zs_conv1_wgrad: too many output positions");
   hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(C1W_BLOCKS), dim3(256), 0, (hipStream_t)stream, *p, Ho, Wo, M);
   int rc = zs_check_launch("zs_conv1_wgrad");
   if (rc) return rc;
-  hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, *p);
+  hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, *p);
   return zs_check_launch("zs_conv1_wgrad.reduce");
 }
 
