@@ -383,3 +383,28 @@ def test_encode_batch_draws_fresh_noise_and_decodes_its_own_bits(cv, tmp_path):
         if prev is not None:
             assert any((a != b).any() for a, b in zip(prev, encs)), 'the Gumbel noise did not change between calls'
         prev = encs
+
+
+def test_resynth_batch_small_and_short_inputs(cv, tmp_path):
+    """resynth_batch on the corner shapes of the fragment rule: a single utterance shorter than seg_len (one ragged chunk, no full
+    fragment), one shorter than MIN_LEN (zero-padded, encodings truncated), one that is an exact multiple of seg_len + 1 (the rule
+    drops the last frame: only full fragments) -- each equal to encode_batch + spectrogram2wav_batch."""
+    from zs_amd.hps import make_hps
+    from zs_amd.trainer import Trainer
+    torch.manual_seed(2)
+    hps = make_hps(enc_size=16, emb_size=32, n_speakers=4, n_target_speakers=2)
+    tr = Trainer(hps, None, 'targeted_residual', 'multilabel_binary', log_dir=str(tmp_path / 'log'), dtype='fp32')
+    rng = np.random.RandomState(3)
+
+    def noise_fn(n, Tp, E):
+        g = torch.Generator().manual_seed(77 + Tp)
+        return -torch.log(-torch.log(torch.rand(n, Tp, E, 2, generator=g) + 1e-20) + 1e-20)
+
+    for lens in ([100], [5, 257], [385, 129, 64]):
+        specs = [np.clip(rng.rand(n, 513).astype(np.float32), 1e-8, 1) for n in lens]
+        spk = [i % 4 for i in range(len(lens))]
+        e0, d0 = cv.encode_batch(specs, tr, 128, decode_speakers=spk, noise_fn=noise_fn)
+        w0 = cv.spectrogram2wav_batch(d0, n_iter=6, do_trim=False)
+        e1, w1 = cv.resynth_batch(specs, tr, 128, spk, n_iter=6, do_trim=False, noise_fn=noise_fn)
+        for a, b, w, w2 in zip(e0, e1, w0, w1):
+            assert np.array_equal(a, b) and np.array_equal(w, w2) and np.isfinite(w2).all()
