@@ -440,6 +440,8 @@ typedef struct {
   const float* mag; const int32_t* lengths; int32_t n_utt, T_max;
   float* wav; int64_t wav_ld;
   int32_t tile_frames;           /* STFT frames per workgroup tile (4..42), 0 = default 10 */
+  const int32_t* host_lengths;   /* optional copy of `lengths` in HOST memory: zs_griffin_lim then cuts its launch chains at equal frame
+                                    counts instead of equal utterance counts (utterances stay in order) */
 } ZsGlIter;
 int zs_gl_iter(const ZsGlIter* p, void* stream);
 int zs_griffin_lim(const ZsGlIter* p, float* spec_a, float* spec_b, int32_t n_iter, void* stream);

@@ -63,8 +63,9 @@ def griffin_lim_batch(mags, n_iter=None, device=None, impl=None, tile_frames=0, 
     wav = torch.zeros(n, wav_ld, dtype=torch.float32, device=dev)
     if impl == 'fused':
         spec_b = torch.empty_like(spec)
+        host_lens = np.asarray(lens, dtype=np.int32)                # the chains of zs_griffin_lim are cut at equal frame counts
         S = L.STRUCTS['ZsGlIter'](mag=L.ptr(mag), lengths=L.ptr(lengths), n_utt=n, T_max=Tm, wav=L.ptr(wav), wav_ld=wav_ld,
-                                  tile_frames=int(tile_frames))
+                                  tile_frames=int(tile_frames), host_lengths=host_lens.ctypes.data)
         L.check(L.lib().zs_griffin_lim(ctypes.addressof(S), L.ptr(spec), L.ptr(spec_b), int(n_iter), st), 'zs_griffin_lim')
         return wav, lengths, lens
     if impl != 'split':

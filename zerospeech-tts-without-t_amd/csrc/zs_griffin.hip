@@ -543,8 +543,26 @@ extern "C" int zs_griffin_lim(const ZsGlIter* p, float* spec_a, float* spec_b, i
   ZsGlIter q[GL_MAX_CHAINS];
   float *cur[GL_MAX_CHAINS], *nxt[GL_MAX_CHAINS];
   hipStream_t cs[GL_MAX_CHAINS];
+  // chain boundaries: equal utterance counts, or -- with the lengths on the host -- equal frame counts (the chains then finish
+  // together; with 64 utterances of 200..700 frames the thirds differ by up to 10 % in frames)
+  int cut[GL_MAX_CHAINS + 1];
+  for (int c = 0; c <= chains; ++c) cut[c] = (int)((int64_t)p->n_utt * c / chains);
+  if (p->host_lengths != nullptr) {
+    int64_t total = 0, run = 0;
+    for (int u = 0; u < p->n_utt; ++u) total += p->host_lengths[u];
+    int c = 1;
+    for (int u = 0; u < p->n_utt && c < chains; ++u) {
+      run += p->host_lengths[u];
+      if (run * chains >= total * c) cut[c++] = u + 1;
+    }
+    for (; c < chains; ++c) cut[c] = p->n_utt;
+    for (c = 1; c < chains; ++c)                                 // every chain keeps at least one utterance
+      if (cut[c] <= cut[c - 1]) cut[c] = cut[c - 1] + 1;
+    for (c = chains - 1; c >= 1; --c)
+      if (cut[c] >= cut[c + 1]) cut[c] = cut[c + 1] - 1;
+  }
   for (int c = 0; c < chains; ++c) {
-    const int u0 = (int)((int64_t)p->n_utt * c / chains), u1 = (int)((int64_t)p->n_utt * (c + 1) / chains);
+    const int u0 = cut[c], u1 = cut[c + 1];
     q[c] = *p;
     q[c].mag = p->mag + u0 * per_utt; q[c].lengths = p->lengths + u0; q[c].n_utt = u1 - u0; q[c].wav = p->wav + (int64_t)u0 * p->wav_ld;
     q[c].tile_frames = F;
