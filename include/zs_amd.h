@@ -445,6 +445,8 @@ typedef struct {
 } ZsGlIter;
 int zs_gl_iter(const ZsGlIter* p, void* stream);
 int zs_griffin_lim(const ZsGlIter* p, float* spec_a, float* spec_b, int32_t n_iter, void* stream);
+/* spec_a / spec_b are SCRATCH for zs_griffin_lim ([n_utt][T_max][513] complex64 each, contents on entry ignored): the loop starts
+ * from X0 = S with zero phase (convert.py:41), which the first iteration reads from `mag` itself. */
 /* zs_griffin_lim issues the loop as up to `gl_chains` (zs_set_option, default 3) independent launch chains over contiguous utterance
  * ranges, on internal streams measured (once per process) to execute side by side, joined back into `stream` before it returns:
  * utterances do not depend on each other, and a chain's partly filled last round of workgroups is filled by the others.  One chain

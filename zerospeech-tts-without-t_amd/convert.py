@@ -57,11 +57,10 @@ def griffin_lim_batch(mags, n_iter=None, device=None, impl=None, tile_frames=0, 
             t = m if torch.is_tensor(m) else torch.as_tensor(np.asarray(m, dtype=np.float32))
             mag[i, :lens[i]] = t.to(dev, torch.float32).t()
     lengths = torch.tensor(lens, dtype=torch.int32, device=dev)
-    spec = torch.zeros(n, Tm, 513, 2, dtype=torch.float32, device=dev)
-    spec[..., 0] = mag                            # X0 = S, zero phase; rows past an utterance's length are never read
     wav_ld = 200 * (Tm - 1)
     wav = torch.zeros(n, wav_ld, dtype=torch.float32, device=dev)
     if impl == 'fused':
+        spec = torch.empty(n, Tm, 513, 2, dtype=torch.float32, device=dev)     # scratch: the first iteration reads X0 = S from `mag`
         spec_b = torch.empty_like(spec)
         host_lens = np.asarray(lens, dtype=np.int32)                # the chains of zs_griffin_lim are cut at equal frame counts
         S = L.STRUCTS['ZsGlIter'](mag=L.ptr(mag), lengths=L.ptr(lengths), n_utt=n, T_max=Tm, wav=L.ptr(wav), wav_ld=wav_ld,
@@ -70,6 +69,8 @@ def griffin_lim_batch(mags, n_iter=None, device=None, impl=None, tile_frames=0, 
         return wav, lengths, lens
     if impl != 'split':
         raise ValueError("griffin_lim impl must be 'fused' or 'split'")
+    spec = torch.zeros(n, Tm, 513, 2, dtype=torch.float32, device=dev)
+    spec[..., 0] = mag                            # X0 = S, zero phase; rows past an utterance's length are never read
     frames = torch.empty(n, Tm, 1024, dtype=torch.float32, device=dev)
     ist = dict(spec=L.ptr(spec), mag=L.ptr(mag), lengths=L.ptr(lengths), n_utt=n, T_max=Tm, wav=L.ptr(wav), wav_ld=wav_ld,
                frames_ws=L.ptr(frames))

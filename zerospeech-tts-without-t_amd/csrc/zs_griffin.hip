@@ -130,7 +130,7 @@ __device__ __forceinline__ int floordiv(int a, int b) { return (a >= 0) ? a / b 
 // PF: request the spectrum of a wave's next inverse frame right behind the current transform (see below).  NWAVE: waves per
 // workgroup (4 or 8): a tile of F frames inverse-transforms F + 6 frames in four phases, so the phases are balanced over the waves
 // when F + 6 is a multiple of 4 NWAVE -- F = 10 with 4 waves (1.6 inverse transforms per frame), F = 26 with 8 waves (1.23).
-template <bool PF, int NWAVE>
+template <bool PF, int NWAVE, bool FROM_MAG>
 __global__ __launch_bounds__(64 * NWAVE) void gl_iter_kernel(const ZsGlIter p, const float* spec_in, float* spec_out, int F) {
   constexpr int NT_ = 64 * NWAVE;
   extern __shared__ __align__(16) unsigned char gl_smem[];
@@ -172,7 +172,14 @@ __global__ __launch_bounds__(64 * NWAVE) void gl_iter_kernel(const ZsGlIter p, c
   // NEXT frame (in this or a later phase) is requested right after the current transform, so its latency runs under the
   // overlap-add, the phase barrier and the other waves' work -- and not during the transform, where the registers are needed.
   float2 xa[8], xb[8];
+  const float* Min = p.mag + (int64_t)u * p.T_max * NB;
   auto fetch = [&](int fi) {
+    if constexpr (FROM_MAG) {                                                  // first iteration: X0 = S, zero phase (convert.py:41)
+      const float* Mx = Min + (int64_t)fi * NB;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { xa[r] = make_float2(Mx[lane + 64 * r], 0.f); xb[r] = make_float2(Mx[HALF - lane - 64 * r], 0.f); }
+      return;
+    }
     const float2* X = Sin + (int64_t)fi * NB;
 #pragma unroll
     for (int r = 0; r < 8; ++r) { xa[r] = X[lane + 64 * r]; xb[r] = X[HALF - lane - 64 * r]; }
@@ -392,24 +399,30 @@ size_t gl_lds_bytes(int F, int nwave) { return (size_t)WTAB * 8 + WLEN * 4 + HOP
 
 void gl_set_lds_attr();
 
-int gl_launch(const ZsGlIter* p, const float* in, float* out, hipStream_t s) {
+int gl_launch(const ZsGlIter* p, const float* in, float* out, hipStream_t s, int from_mag = 0) {
   // default tile: 26 frames on 8 waves once the batch fills the chip (>= 8192 frames: 1.23 instead of 1.6 inverse transforms per
   // frame, 29.2 against 30.9 ms for 300 iterations of 64 utterances of 200..700 frames), else 10 frames on 4 waves (more workgroups)
   const int F = p->tile_frames > 0 ? p->tile_frames : ((int64_t)p->n_utt * p->T_max >= 8192 ? GL_TILE_LARGE : GL_TILE_DEFAULT);
   dim3 grid((unsigned)((p->T_max + F - 1) / F), (unsigned)p->n_utt);
   const bool pf = g_gl_prefetch.load(std::memory_order_relaxed) != 0;
+#define ZS_GL_LAUNCH(PFV, NW, FM) hipLaunchKernelGGL((gl_iter_kernel<PFV, NW, FM>), grid, dim3(64 * NW), gl_lds_bytes(F, NW), s, *p, in, out, F)
+  // FROM_MAG (the first iteration reads X0 = S from the magnitudes) is a template parameter: as a run-time branch it took the
+  // steady-state kernel over 128 VGPRs, i.e. from two workgroups per CU to one (26 -> 39 ms)
   if (F > 16) {                                                               // large tiles: 8 waves share the segment
     std::call_once(g_gl_lds_once, gl_set_lds_attr);
-    if (pf) hipLaunchKernelGGL((gl_iter_kernel<true, 8>), grid, dim3(512), gl_lds_bytes(F, 8), s, *p, in, out, F);
-    else hipLaunchKernelGGL((gl_iter_kernel<false, 8>), grid, dim3(512), gl_lds_bytes(F, 8), s, *p, in, out, F);
-  } else if (pf) hipLaunchKernelGGL((gl_iter_kernel<true, 4>), grid, dim3(256), gl_lds_bytes(F, 4), s, *p, in, out, F);
-  else hipLaunchKernelGGL((gl_iter_kernel<false, 4>), grid, dim3(256), gl_lds_bytes(F, 4), s, *p, in, out, F);
+    if (from_mag) { if (pf) ZS_GL_LAUNCH(true, 8, true); else ZS_GL_LAUNCH(false, 8, true); }
+    else { if (pf) ZS_GL_LAUNCH(true, 8, false); else ZS_GL_LAUNCH(false, 8, false); }
+  } else if (from_mag) { if (pf) ZS_GL_LAUNCH(true, 4, true); else ZS_GL_LAUNCH(false, 4, true); }
+  else { if (pf) ZS_GL_LAUNCH(true, 4, false); else ZS_GL_LAUNCH(false, 4, false); }
+#undef ZS_GL_LAUNCH
   return zs_check_launch("zs_gl_iter");
 }
 
 void gl_set_lds_attr() {                                                      // 8-wave tiles of F = 42 frames need 79 KB of LDS
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gl_iter_kernel<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gl_iter_kernel<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gl_iter_kernel<true, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gl_iter_kernel<false, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gl_iter_kernel<true, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gl_iter_kernel<false, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
 }
 
 int gl_check(const ZsGlIter* p, const char* what) {
@@ -506,11 +519,11 @@ int gl_chain(const ZsGlIter& q, float* spec_a, float* spec_b, int n_iter, hipStr
   float* cur = spec_a;
   float* nxt = spec_b;
   for (int it = 0; it < n_iter; ++it) {
-    int rc = gl_launch(&q, cur, nxt, s);
+    int rc = gl_launch(&q, cur, nxt, s, it == 0);
     if (rc) return rc;
     float* t = cur; cur = nxt; nxt = t;
   }
-  return gl_launch(&q, cur, nullptr, s);
+  return gl_launch(&q, cur, nullptr, s, n_iter == 0);
 }
 
 }  // namespace
@@ -572,7 +585,7 @@ extern "C" int zs_griffin_lim(const ZsGlIter* p, float* spec_a, float* spec_b, i
   }
   for (int it = 0; it <= n_iter; ++it)
     for (int c = 0; c < chains; ++c) {
-      rc = gl_launch(&q[c], cur[c], it < n_iter ? nxt[c] : nullptr, cs[c]);
+      rc = gl_launch(&q[c], cur[c], it < n_iter ? nxt[c] : nullptr, cs[c], it == 0);
       if (rc) return rc;
       float* t = cur[c]; cur[c] = nxt[c]; nxt[c] = t;
     }
