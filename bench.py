@@ -316,10 +316,10 @@ def resynth_record(args, rank, world, dev, steps, warmup, cpu=True):
         # counters are per kernel launch; an iteration of all utterances is (launches of gl_iter_kernel) / (batches x (n_iter + 1)) of
         # them -- one under the counter passes (the profiler serialises kernels, so the stream probe finds no concurrency and
         # zs_griffin_lim stays on one chain), `chains` otherwise.  Batches of the profiled run = launches of the de-emphasis scan.
-        gk = next((v for k, v in kk.items() if k.startswith('gl_iter_kernel')), None)
+        gks = [v for k, v in kk.items() if k.startswith('gl_iter_kernel')]          # (the first-iteration variant is a kernel of its own)
         nb = next((v.get('launches') for k, v in kk.items() if k.startswith('gl_deemph_scan_kernel')), None)
-        if gk is not None and nb:
-            gl_traffic = gk['traffic_bytes_per_launch'] * gk['launches'] / float(nb * (n_iter + 1))
+        if gks and nb:
+            gl_traffic = sum(v['traffic_bytes_per_launch'] * v['launches'] for v in gks) / float(nb * (n_iter + 1))
     fl = out_frames * (2 * n_iter + 1) * 2.5 * 1024 * 10          # per rank-0 shard
     by = out_frames * 513.0 * (8 + 8 + 4)                         # algorithmic bytes per launch: spectrum in + out, magnitudes in
     launch_s = gl / (n_iter + 1)
