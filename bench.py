@@ -284,6 +284,19 @@ def resynth_record(args, rank, world, dev, steps, warmup, cpu=True):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     layers.check_status(dev)
+    # the same batches as a serving loop issues them: batch i + 1 enqueued before the results of batch i are waited for
+    # (resynth_batch(defer=True)); reported beside `value`, which keeps one host wait per batch inside every step
+    pend = None
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        f = cv.resynth_batch(specs_dev, tr, 128, spk, n_iter=n_iter, do_trim=True, defer=True)
+        if pend is not None:
+            pend()
+        pend = f
+    pend()
+    torch.cuda.synchronize()
+    dt_pipe = (time.perf_counter() - t1) / steps
     # beside it: the same batch handed over as host arrays (the reference's loader), pinned staging + H2D inside the time
     run(False, specs)
     torch.cuda.synchronize()
@@ -331,7 +344,8 @@ def resynth_record(args, rank, world, dev, steps, warmup, cpu=True):
                                   '(Griffin-Lim n_iter=%d, de-emphasis, trim) of %d utterances of U{200..700} frames per GPU, spectrograms '
                                   'resident in HBM, host fragmenting and D2H of the results included' % (n_iter, len(lens)), 'parallelism': 'replicas%d' % world},
            'frames_per_s': float(sum(lens_all)) * steps / dt, 'host_input_utt_per_s': len(lens_all) / dt_host,
-           'host_input_ms_per_step': 1e3 * dt_host, 'encode_decode_ms': 1e3 * dt_enc, 'griffin_lim_ms': 1e3 * gl,
+           'host_input_ms_per_step': 1e3 * dt_host, 'pipelined_utt_per_s': len(lens_all) / dt_pipe, 'pipelined_ms_per_step': 1e3 * dt_pipe,
+           'encode_decode_ms': 1e3 * dt_enc, 'griffin_lim_ms': 1e3 * gl,
            'roofline': {'bound': 'hbm', 'achieved': by / launch_s / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': by / launch_s / 8e12,
                         'traffic': gl_traffic, 'traffic_unit': 'bytes/launch (committed rocprofv3 --pmc passes of this command)',
                         'kernel': 'gl_iter_kernel (one fused Griffin-Lim iteration of ALL utterances = one "launch" here; issued as up to 3 '

@@ -408,3 +408,12 @@ def test_resynth_batch_small_and_short_inputs(cv, tmp_path):
         e1, w1 = cv.resynth_batch(specs, tr, 128, spk, n_iter=6, do_trim=False, noise_fn=noise_fn)
         for a, b, w, w2 in zip(e0, e1, w0, w1):
             assert np.array_equal(a, b) and np.array_equal(w, w2) and np.isfinite(w2).all()
+    # two batches in flight (defer=True: batch 2 is enqueued before batch 1 is waited for) give what they give one at a time
+    sa = [np.clip(rng.rand(n, 513).astype(np.float32), 1e-8, 1) for n in (300, 140)]
+    sb = [np.clip(rng.rand(n, 513).astype(np.float32), 1e-8, 1) for n in (129, 260, 90)]
+    ra = cv.resynth_batch(sa, tr, 128, [0, 1], n_iter=6, noise_fn=noise_fn)
+    rb = cv.resynth_batch(sb, tr, 128, [2, 3, 0], n_iter=6, noise_fn=noise_fn)
+    fa = cv.resynth_batch(sa, tr, 128, [0, 1], n_iter=6, noise_fn=noise_fn, defer=True)
+    fb = cv.resynth_batch(sb, tr, 128, [2, 3, 0], n_iter=6, noise_fn=noise_fn, defer=True)
+    for (e_ref, w_ref), (e_got, w_got) in ((ra, fa()), (rb, fb())):
+        assert all(np.array_equal(a, b) for a, b in zip(e_ref, e_got)) and all(np.array_equal(a, b) for a, b in zip(w_ref, w_got))

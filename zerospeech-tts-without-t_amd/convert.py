@@ -144,9 +144,14 @@ def _enqueue_vocoder(t, lens, n_iter, do_trim, dev):
                 'zs_gl_frame_mse')
         mse_h = _to_host(mse)
     w_h = _to_host(wav)
+    from . import layers
+    st_h = _to_host(layers.device_status(dev))                # the sticky GRU status word as of this batch (checked by the caller)
+    done = torch.cuda.Event()
+    done.record(torch.cuda.current_stream(dev))
 
     def finish():
-        torch.cuda.current_stream(dev).synchronize()
+        done.synchronize()                                    # this batch's copies only: later batches may already be enqueued
+        finish.status = int(st_h[0])
         w = w_h.numpy()
         out = []
         for i, T in enumerate(lens):
@@ -449,12 +454,15 @@ def encode_batch(specs, trainer, seg_len, decode_speakers=None, noise_fn=None, m
     return _assemble(q, None if decode_speakers is None else ('host' if to_host else 'device'))
 
 
-def resynth_batch(specs, trainer, seg_len, speakers, n_iter=None, do_trim=True, noise_fn=None, max_batch=256):
+def resynth_batch(specs, trainer, seg_len, speakers, n_iter=None, do_trim=True, noise_fn=None, max_batch=256, defer=False):
     """test_encode + convert(enc_only) + spectrogram2wav for a batch of utterances as ONE enqueue (convert.py:151-165, 55-62):
     the fragments' Encoder / Decoder launches, the gather of the decoded fragments into the vocoder's padded [n, T_max, 513]
     input (one index kernel on the device), de-normalisation, the Griffin-Lim loop, de-emphasis, the trim statistics and the
     D2H copies go onto the stream back to back; the host assembles the encodings while the vocoder runs and waits ONCE.
-    Returns (encodings list, wav list) -- the same values as encode_batch(...) followed by spectrogram2wav_batch(...)."""
+    Returns (encodings list, wav list) -- the same values as encode_batch(...) followed by spectrogram2wav_batch(...).
+    defer=True returns a function instead that waits for THIS batch (an event behind its last copy) and returns that pair: a
+    serving loop enqueues batch i + 1 before it calls the function of batch i, so the host-side assembly and the D2H copies of one
+    batch run under the GPU work of the next."""
     q = _enqueue_encode(specs, trainer, seg_len, speakers, noise_fn, max_batch, dec_to_host=False)
     dev = q.dev
     # row table of all decoded fragments + a zero row; utterance u's frames are its fragments' rows in order
@@ -481,12 +489,16 @@ def resynth_batch(specs, trainer, seg_len, speakers, n_iter=None, do_trim=True, 
     table = torch.cat([x.reshape(-1, x.shape[2]) for x in q.dec_dev] + [torch.zeros(1, q.dec_dev[0].shape[2], dtype=q.dec_dev[0].dtype, device=dev)], dim=0)
     t = table[torch.from_numpy(idx).to(dev, non_blocking=True)].float()                               # [n, Tm, 513]
     fin = _enqueue_vocoder(t, ulens, n_iter, do_trim, dev)
-    q.enc_done.synchronize()                                  # the encodings are on the host; the vocoder is still running
-    encs, _ = _assemble(q, None)
-    wavs = fin()
-    from . import layers
-    layers.check_status(dev)
-    return encs, wavs
+
+    def finish():
+        q.enc_done.synchronize()                              # the encodings are on the host; the vocoder is still running
+        encs, _ = _assemble(q, None)
+        wavs = fin()
+        if fin.status:                                        # a persistent GRU pass timed out before this batch's end
+            from . import layers
+            layers.check_status(dev)                          # synchronises, clears the word and raises
+        return encs, wavs
+    return finish if defer else finish()
 
 
 def write_wav(path, wav, sr):
