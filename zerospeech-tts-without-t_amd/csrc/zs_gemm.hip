@@ -137,15 +137,15 @@ __device__ __forceinline__ void store_group(OT* base, int64_t row, int64_t ld, i
   }
 }
 
-template <typename T, int NTHREADS>
+template <typename T, int NTHREADS, int ROWS = NTHREADS / 2>
 __device__ __forceinline__ void epilogue_finish(const ZsGemmConv& p, const float* sC, int M, int m0, int n0, int tid, int g);
 
 // per-sample column sums of the staged [NTHREADS/2 rows][128 columns] fp32 tile (ZsGemmConv.colsum; the host admits it only
 // without bias / pre_vec / activation, so the staged accumulators are the values): whole samples per tile, one owner per (b, n)
-template <int NTHREADS>
+template <int NTHREADS, int ROWS = NTHREADS / 2>
 __device__ __forceinline__ void epilogue_colsum(const ZsGemmConv& p, const float* sC, int M, int m0, int n0, int tid) {
   if (p.colsum == nullptr) return;
-  const int ns = (NTHREADS / 2) / p.T_out;
+  const int ns = ROWS / p.T_out;
   for (int w = tid; w < ns * 128; w += NTHREADS) {
     const int col = w & 127, r0 = (w >> 7) * p.T_out;
     const int n = n0 + col, m = m0 + r0;
@@ -171,29 +171,32 @@ __device__ __forceinline__ void epilogue_colsum(const ZsGemmConv& p, const float
   }
 }
 
-template <typename T, int NTHREADS>
-__device__ __forceinline__ void gemm_epilogue(const ZsGemmConv& p, f32x16 (&acc)[2][2], float* sC, int M, int m0, int n0,
+// MI: 32-row MFMA tiles per wave along M (2: the NTHREADS/2-row tile; 1: the 64-row tile of gemm_conv_dma_kernel<T, 64>)
+template <typename T, int NTHREADS, int MI = 2>
+__device__ __forceinline__ void gemm_epilogue(const ZsGemmConv& p, f32x16 (&acc)[MI][2], float* sC, int M, int m0, int n0,
                                               int wm, int wn, int tid, int g) {
+  constexpr int ROWS = (NTHREADS / 2) * MI / 2;
   const int lane = tid & 63;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int row = wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int col = wn * 64 + ni * 32 + (lane & 31);
         sC[row * CPITCH + col] = acc[mi][ni][r];
       }
   __syncthreads();
-  epilogue_colsum<NTHREADS>(p, sC, M, m0, n0, tid);
-  epilogue_finish<T, NTHREADS>(p, sC, M, m0, n0, tid, g);
+  epilogue_colsum<NTHREADS, ROWS>(p, sC, M, m0, n0, tid);
+  epilogue_finish<T, NTHREADS, ROWS>(p, sC, M, m0, n0, tid, g);
 }
 
-// finishes the staged [NTHREADS/2 rows][128 columns] fp32 tile at (m0, n0)
-template <typename T, int NTHREADS>
+// finishes the staged [ROWS rows][128 columns] fp32 tile at (m0, n0)
+template <typename T, int NTHREADS, int ROWS>
 __device__ __forceinline__ void epilogue_finish(const ZsGemmConv& p, const float* sC, int M, int m0, int n0, int tid, int g) {
-  constexpr int ROWS_PER_PASS = NTHREADS / 16;      // 128-row tile with 256 threads, 256-row tile with 512: 8 passes
+  constexpr int ROWS_PER_PASS = NTHREADS / 16;      // 128-row tile with 256 threads, 256-row tile with 512: 8 passes; 64-row tile: 4
+  constexpr int PASSES = ROWS / ROWS_PER_PASS;
   const int cg = tid & 15, rr0 = tid >> 4;          // 16 column groups x 16 rows per pass, 8 passes
   const int n = n0 + cg * 8;
   if (n >= p.N && n >= p.out_cols && n >= p.out2_cols) return;
@@ -213,7 +216,7 @@ __device__ __forceinline__ void epilogue_finish(const ZsGemmConv& p, const float
   T* outt = (T*)p.out + (p.out_f32 ? 0 : (int64_t)g * p.out_gstride);
 
 #pragma unroll 2
-  for (int it = 0; it < 8; ++it) {
+  for (int it = 0; it < PASSES; ++it) {
     const int row = rr0 + ROWS_PER_PASS * it;
     const int m = m0 + row;
     if (m >= M) break;
@@ -471,14 +474,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_conv_kernel(const ZsGemmConv p) {
 // ------------------------------------------------------------------------------------------------
 constexpr int DTILE = 128 * 128;   // bytes per operand tile
 
-template <typename T>
+// BM_ = 128: the tile above.  BM_ = 64: half the rows per workgroup (waves 2 x 2 of 32 x 64) for layers whose 128-row grid leaves
+// half the chip idle (the T' = 16 layers: M = 4096, N = 512 -> 128 workgroups of 128 rows, 256 of 64).
+template <typename T, int BM_>
 __global__ __launch_bounds__(NT, 2) void gemm_conv_dma_kernel(const ZsGemmConv p) {
+  constexpr int MI = BM_ / 64, AI = BM_ / 32, ATILE = BM_ * 128;
   const Geom2 g2 = make_geom2(p.w_in, p.w_out, p.taps_h, p.T_in);
   constexpr int EPS = 16 / (int)sizeof(T);
   constexpr int KC = ROWB / (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sA = smem;                 // [2][DTILE]
-  unsigned char* sB = smem + 2 * DTILE;     // [2][DTILE]
+  unsigned char* sA = smem;                 // [2][ATILE]
+  unsigned char* sB = smem + 2 * ATILE;     // [2][DTILE]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int g = blockIdx.z;
@@ -486,14 +492,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_conv_dma_kernel(const ZsGemmConv p
   const T* __restrict__ W = (const T*)p.W + (int64_t)g * p.w_gstride;
   const int M = p.B * p.T_out;
   const int ntn = (p.N + BN - 1) / BN;
-  const int ntm = (M + BM - 1) / BM;
+  const int ntm = (M + BM_ - 1) / BM_;
   const int wg = xcd_remap(blockIdx.x, ntm * ntn);
   constexpr int GM = 8;
   const int per_group = GM * ntn;
   const int grp = wg / per_group;
   const int gm = min(GM, ntm - grp * GM);
   const int in_g = wg - grp * per_group;
-  const int m0 = (grp * GM + in_g % gm) * BM, n0 = (in_g / gm) * BN;
+  const int m0 = (grp * GM + in_g % gm) * BM_, n0 = (in_g / gm) * BN;
 
   // loader: wave-instruction i of this wave fills tile rows wave*32 + 8i .. +7 (lane>>3 selects the row,
   // lane&7 the physical slot); the logical segment it must fetch is slot ^ ((row>>1)&7)
@@ -502,10 +508,18 @@ __global__ __launch_bounds__(NT, 2) void gemm_conv_dma_kernel(const ZsGemmConv p
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = wave * 32 + i * 8 + lrow;
-    lseg[i] = slot ^ ((r >> 1) & 7);
-    const int m = m0 + r;
-    conv_row_setup(p, m, M, rb[i], rt[i]);
+    lseg[i] = slot ^ ((r >> 1) & 7);               // (rows of the W tile; the A rows of a 64-row tile: see aseg)
+    rb[i] = -1; rt[i] = 0;
   }
+  int aseg[4];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int r = wave * (8 * AI) + i * 8 + lrow;
+    aseg[i] = slot ^ ((r >> 1) & 7);
+    conv_row_setup(p, m0 + r, M, rb[i], rt[i]);
+  }
+#pragma unroll
+  for (int i = AI; i < 4; ++i) aseg[i] = 0;
   const int chunks_per_tap = p.cin_pad / KC;
   const T* zline = reinterpret_cast<const T*>(zs_zero_line);
   const T *pa0, *pa1, *pa2, *pa3;
@@ -514,7 +528,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_conv_dma_kernel(const ZsGemmConv p
   {                                                                                                     \
     bool ok = false; int srow = 0;                                                                      \
     if (rb[i] >= 0) srow = conv_src_row_g(p.gather, p.pad_mode, p.stride, p.pad_left, conv_row_tin(p, rb[i]), rt[i], tap, ok, g2); \
-    ptr = ok ? (A + (int64_t)conv_row_b(p, rb[i]) * p.a_batch_stride + (int64_t)srow * p.lda + lseg[i] * EPS) : (zline + lseg[i] * EPS); \
+    ptr = ok ? (A + (int64_t)conv_row_b(p, rb[i]) * p.a_batch_stride + (int64_t)srow * p.lda + aseg[i] * EPS) : (zline + aseg[i] * EPS); \
     inc = ok ? KC : 0;                                                                                  \
   }
   const T* pw0 = W + (int64_t)(n0 + wave * 32 + lrow) * p.ldw + lseg[0] * EPS;
@@ -523,16 +537,19 @@ __global__ __launch_bounds__(NT, 2) void gemm_conv_dma_kernel(const ZsGemmConv p
   const T* pw3 = W + (int64_t)(n0 + wave * 32 + 24 + lrow) * p.ldw + lseg[3] * EPS;
   const int nk = p.taps * chunks_per_tap;
   int tap = 0, cit = 0;
-  { ZS_SET_TAP(0, pa0, inc0) ZS_SET_TAP(1, pa1, inc1) ZS_SET_TAP(2, pa2, inc2) ZS_SET_TAP(3, pa3, inc3) }
+  pa2 = pa3 = zline; inc2 = inc3 = 0;
+  { ZS_SET_TAP(0, pa0, inc0) ZS_SET_TAP(1, pa1, inc1) if (AI == 4) { ZS_SET_TAP(2, pa2, inc2) ZS_SET_TAP(3, pa3, inc3) } }
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   auto dma = [&](int buf) {
-    unsigned char* da = sA + buf * DTILE + wave * 4096;   // this wave's 32 rows
-    unsigned char* db = sB + buf * DTILE + wave * 4096;
+    unsigned char* da = sA + buf * ATILE + wave * (1024 * AI);   // this wave's 8 AI rows of A
+    unsigned char* db = sB + buf * DTILE + wave * 4096;          // ... and 32 rows of W
     __builtin_amdgcn_global_load_lds((gptr_t)pa0, (lptr_t)(da), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gptr_t)pa1, (lptr_t)(da + 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)pa2, (lptr_t)(da + 2048), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)pa3, (lptr_t)(da + 3072), 16, 0, 0);
+    if (AI == 4) {
+      __builtin_amdgcn_global_load_lds((gptr_t)pa2, (lptr_t)(da + 2048), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)pa3, (lptr_t)(da + 3072), 16, 0, 0);
+    }
     __builtin_amdgcn_global_load_lds((gptr_t)pw0, (lptr_t)(db), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gptr_t)pw1, (lptr_t)(db + 1024), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gptr_t)pw2, (lptr_t)(db + 2048), 16, 0, 0);
@@ -540,22 +557,22 @@ __global__ __launch_bounds__(NT, 2) void gemm_conv_dma_kernel(const ZsGemmConv p
     pw0 += KC; pw1 += KC; pw2 += KC; pw3 += KC;
     if (++cit == chunks_per_tap) {
       cit = 0; ++tap;
-      if (tap < p.taps) { ZS_SET_TAP(0, pa0, inc0) ZS_SET_TAP(1, pa1, inc1) ZS_SET_TAP(2, pa2, inc2) ZS_SET_TAP(3, pa3, inc3) }
+      if (tap < p.taps) { ZS_SET_TAP(0, pa0, inc0) ZS_SET_TAP(1, pa1, inc1) if (AI == 4) { ZS_SET_TAP(2, pa2, inc2) ZS_SET_TAP(3, pa3, inc3) } }
     } else {
       pa0 += inc0; pa1 += inc1; pa2 += inc2; pa3 += inc3;
     }
   };
 #undef ZS_SET_TAP
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // fragment addresses: row = w*64 + mi*32 + (lane&31); logical segment 2*ks + (lane>>5); slot = seg ^ ((row>>1)&7)
+  // fragment addresses: row = w*(32 MI) + mi*32 + (lane&31); logical segment 2*ks + (lane>>5); slot = seg ^ ((row>>1)&7)
   const int frow = lane & 31, fh = lane >> 5;
   const int fx = (frow >> 1) & 7;             // same for row and row+32 (32>>1 = 16, &7 = 0)
   dma(0);
@@ -565,14 +582,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_conv_dma_kernel(const ZsGemmConv p
     const int buf = kt & 1;
     // 1) all fragments of chunk kt into registers FIRST: hipcc orders any ds_read that follows an LDS-DMA behind
     //    vmcnt(0) (it cannot tell the two buffers apart), which would serialise the DMA with the MFMAs
-    const unsigned char* a_base = sA + buf * DTILE + (wm * 64 + frow) * 128;
+    const unsigned char* a_base = sA + buf * ATILE + (wm * (32 * MI) + frow) * 128;
     const unsigned char* b_base = sB + buf * DTILE + (wn * 64 + frow) * 128;
     uint4 fa[4][2], fb[4][2];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int off = ((2 * ks + fh) ^ fx) * 16;
       fa[ks][0] = *reinterpret_cast<const uint4*>(a_base + off);
-      fa[ks][1] = *reinterpret_cast<const uint4*>(a_base + 32 * 128 + off);
+      if (MI == 2) fa[ks][1] = *reinterpret_cast<const uint4*>(a_base + 32 * 128 + off);
       fb[ks][0] = *reinterpret_cast<const uint4*>(b_base + off);
       fb[ks][1] = *reinterpret_cast<const uint4*>(b_base + 32 * 128 + off);
     }
@@ -582,14 +599,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_conv_dma_kernel(const ZsGemmConv p
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) Mma<T>::run(fa[ks][mi], fb[ks][ni], acc[mi][ni]);
     __builtin_amdgcn_sched_barrier(0);                 // keep the MFMAs above the wait (register-only ops float past asm)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
     __syncthreads();                                   // ... and everyone else's
   }
-  gemm_epilogue<T, NT>(p, acc, reinterpret_cast<float*>(smem), M, m0, n0, wm, wn, tid, g);
+  gemm_epilogue<T, NT, MI>(p, acc, reinterpret_cast<float*>(smem), M, m0, n0, wm, wn, tid, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1851,6 +1868,8 @@ struct Knob {
   }
   int set(int nv) { const int old = get(); v.store(nv < 0 ? 0 : nv, std::memory_order_relaxed); return old; }
 };
+Knob g_dma64("ZS_GEMM_DMA64", 1);                 // 64-row tiles of the LDS-DMA kernel for under-filled grids
+Knob g_dma64_max_tiles("ZS_GEMM_DMA64_MAX_TILES", 256);   // ... when twice the 128-row tile count is at most this
 Knob g_wgrad_p8("ZS_WGRAD_P8", 1);
 Knob g_wgrad_wgs("ZS_WGRAD_WGS", 256);      // workgroups one weight-gradient launch aims for (split-K plan of the 256x256 kernel)
 // workgroups a 128x128 weight-gradient launch aims for.  768 (three per CU-pair slot) is best for a launch alone; the launches of
@@ -1992,9 +2011,18 @@ extern "C" int zs_gemm_conv(const ZsGemmConv* p, void* stream) {
       else hipLaunchKernelGGL((gemm_conv_ring_kernel<bf16_t, 0>), rgrid, dim3(RNT), RING_LDS, s, *p);
     }
   } else if (use_dma) {
+    // 64-row tiles where the 128-row grid would leave half the chip without a workgroup
+    const int64_t tiles64 = ((M + 63) / 64) * ((p->N + BN - 1) / BN);
+    if (g_dma64.get() && tiles * 2 <= g_dma64_max_tiles.get() && tiles64 < (1ll << 31) && (p->colsum == nullptr || 64 % p->T_out == 0)) {
+      dim3 g64((unsigned)tiles64, 1, (unsigned)groups);
+      const size_t lds = (2 * 64 * 128 + 2 * DTILE > EPI_LDS_BYTES / 2) ? 2 * 64 * 128 + 2 * DTILE : EPI_LDS_BYTES / 2;
+      if (p->dtype == ZS_F32) hipLaunchKernelGGL((gemm_conv_dma_kernel<float, 64>), g64, dim3(NT), lds, s, *p);
+      else hipLaunchKernelGGL((gemm_conv_dma_kernel<bf16_t, 64>), g64, dim3(NT), lds, s, *p);
+      return zs_check_launch("zs_gemm_conv");
+    }
     const size_t lds = (4 * DTILE > EPI_LDS_BYTES) ? 4 * DTILE : EPI_LDS_BYTES;
-    if (p->dtype == ZS_F32) hipLaunchKernelGGL(gemm_conv_dma_kernel<float>, grid, dim3(NT), lds, s, *p);
-    else hipLaunchKernelGGL(gemm_conv_dma_kernel<bf16_t>, grid, dim3(NT), lds, s, *p);
+    if (p->dtype == ZS_F32) hipLaunchKernelGGL((gemm_conv_dma_kernel<float, 128>), grid, dim3(NT), lds, s, *p);
+    else hipLaunchKernelGGL((gemm_conv_dma_kernel<bf16_t, 128>), grid, dim3(NT), lds, s, *p);
   } else {
     const size_t lds = 4 * TILE_BYTES;
     if (p->dtype == ZS_F32) hipLaunchKernelGGL(gemm_conv_kernel<float>, grid, dim3(NT), lds, s, *p);
@@ -2011,6 +2039,8 @@ extern "C" int zs_set_option(const char* key, int value) {
   else if (key && !strcmp(key, "gemm_pp")) slot = &g_use_pp;
   else if (key && !strcmp(key, "gemm_p8")) slot = &g_use_p8;
   else if (key && !strcmp(key, "gemm_p8_min_tiles")) slot = &g_p8_min_tiles;
+  else if (key && !strcmp(key, "gemm_dma64")) slot = &g_dma64;
+  else if (key && !strcmp(key, "gemm_dma64_max_tiles")) slot = &g_dma64_max_tiles;
   else if (key && !strcmp(key, "wgrad_p8")) slot = &g_wgrad_p8;
   else if (key && !strcmp(key, "wgrad_wgs")) slot = &g_wgrad_wgs;
   else if (key && !strcmp(key, "wgrad_wgs128")) slot = &g_wgrad_wgs128;
