@@ -180,8 +180,12 @@ class PatchEngine(object):
             c.gWv.zero_()
         for h in (self.head_val, self.head_clf):
             h.gWv.zero_()
-        for k, g in self.G.items():
-            g.zero_()
+        bases = {id(g._base): g._base for g in self.G.values()}
+        if len(bases) == 1 and None not in [g._base for g in self.G.values()]:
+            next(iter(bases.values())).zero_()                     # the views tile the net's flat gradient buffer: one fill
+        else:
+            for k, g in self.G.items():
+                g.zero_()
 
     def flush_grads(self):
         """End of a step: virtual weight gradients -> the parameters' gradient views (reference layouts)."""
